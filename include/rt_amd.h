@@ -1,0 +1,216 @@
+/*
+ * rt_amd.h -- C ABI of librt_amd.so, the MI355X (gfx950) implementation of the
+ * ray-triangle hot path of SimonBuan/Raytracer.
+ *
+ * Two groups of entry points:
+ *
+ *  1. The reference's own device API, unchanged (kernel.h:10-17): mat_mult_device and
+ *     intersect_all_triangles_device, host pointers in and out, synchronous, no error
+ *     channel.  A program built against the reference's kernel.h links against this library
+ *     instead of mat_mult.cu / triangle_intersection.cu with no source change.
+ *
+ *  2. An additive batched API (rt_*) that replaces the reference's host-serial pixel loop
+ *     (driver.c:126-193) by whole-band launches over a device-resident scene.  Every rt_*
+ *     function returns 0 on success or a negative RT_E_* code; rt_last_error() gives the
+ *     text.  Nothing here aborts the process.
+ *
+ * Plain pointers and sizes only.  "host" / "device" in a parameter comment says which
+ * address space the pointer must belong to.  All calls are blocking unless stated, and the
+ * library is single-caller like the reference (one host thread per process and GPU).
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stdint.h>
+#include "rt_reference_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status codes */
+#define RT_OK            0
+#define RT_E_ARG        -1   /* bad argument (null pointer, negative size, index out of range) */
+#define RT_E_HIP        -2   /* a HIP runtime call failed; see rt_last_error()                 */
+#define RT_E_STATE      -3   /* call order (e.g. tracing a scene that was never transformed)   */
+#define RT_E_IO         -4   /* file could not be opened / parsed                              */
+#define RT_E_NODEVICE   -5   /* no gfx950 device visible                                       */
+#define RT_E_LIMIT      -6   /* a documented size limit was exceeded                           */
+
+#define RT_MAX_LIGHTS 100    /* light_model.c:9-12 */
+
+/* ------------------------------------------------------------------ 1. reference API */
+
+/* kernel.h:10-14 / mat_mult.cu:31-78.  (X,Y,Z)[i] = rows 0..2 of m applied to (x,y,z,1)[i]
+ * for i in [0,numpoints), fp64, left-to-right sums; outputs may alias inputs.  Host pointers. */
+void mat_mult_device(double* X, double* Y, double* Z, double m[4][4],
+                     double* x, double* y, double* z, int numpoints);
+
+/* kernel.h:16-17 / triangle_intersection.cu:98-190.  One ray S->E against num_tris
+ * triangles.  Returns the index of the triangle with the smallest t > 0 (lowest index on a
+ * tie) or -1; on a hit uv[] and point[] are written, on a miss they are left alone.  Host
+ * pointers.  The device copy of the mesh is kept between calls and refreshed when
+ * mat_mult_device rewrites x/y/z or rt_legacy_invalidate() is called. */
+int intersect_all_triangles_device(double S[3], double E[3], double uv[2], double point[3],
+                                   Triangle* tris, double* x, double* y, double* z,
+                                   int num_tris);
+
+/* Drop the cached device copy used by intersect_all_triangles_device (call after editing
+ * tris or x/y/z by any means other than mat_mult_device). */
+void rt_legacy_invalidate(void);
+/* sizeof(Triangle) of the caller's build when it differs from this header's (0 = default). */
+void rt_set_triangle_stride(int bytes);
+
+/* ------------------------------------------------------------------ 2. batched API */
+
+int         rt_init(int device_ordinal);         /* selects the GPU for this process */
+void        rt_shutdown(void);
+int         rt_device_count(void);               /* number of visible HIP devices (0 if none) */
+const char* rt_last_error(void);
+const char* rt_version(void);
+int         rt_set_stream(void* hip_stream);     /* NULL = the default stream */
+
+typedef struct rt_scene rt_scene;                /* device-resident mesh, opaque */
+
+/* Lights and matrices of one frame: the light_model.h:4-8 globals plus the obinv of
+ * driver.c:107 that interpolate_normal_vector consumes. */
+typedef struct rt_frame {
+    int    num_lights;
+    double light_in_eye_space[RT_MAX_LIGHTS][3];
+    double light_rgb[RT_MAX_LIGHTS][3];
+    double light_attenuation[RT_MAX_LIGHTS][2];
+    double light_max_dist[RT_MAX_LIGHTS];
+    double obmat[4][4];      /* object -> eye  (driver.c:106) */
+    double obinv[4][4];      /* eye -> object  (driver.c:107) */
+} rt_frame;
+
+int rt_scene_create(rt_scene** out);
+int rt_scene_destroy(rt_scene* sc);
+
+/* Geometry upload (host pointers).  Arrays are 1-indexed like obj_reader.h:41-46: length
+ * count+1, slot 0 ignored.  Indices are validated against the counts. */
+int rt_scene_set_vertices(rt_scene* sc, int num_v, const double* x, const double* y, const double* z);
+int rt_scene_set_normals(rt_scene* sc, int num_vn, const double* xn, const double* yn, const double* zn);
+int rt_scene_set_texcoords(rt_scene* sc, int num_vt, const double* u, const double* v);
+/* At/Bt/Ct and mtl may be NULL (no texture coordinates / every triangle mtl.index = -1). */
+int rt_scene_set_triangles(rt_scene* sc, int num_tris,
+                           const int* A, const int* B, const int* C,
+                           const int* An, const int* Bn, const int* Cn,
+                           const int* At, const int* Bt, const int* Ct,
+                           const int* mtl);
+/* Same from the reference's array-of-structures (obj_reader.h:25-39); the per-triangle
+ * Material copies are folded back into a table keyed by mtl.index. */
+int rt_scene_set_triangles_aos(rt_scene* sc, const Triangle* tris, int num_tris);
+/* Ka/Kd/Ks: 3*num_mats doubles each.  map_*: texture index per material or -1; may be NULL. */
+int rt_scene_set_materials(rt_scene* sc, int num_mats,
+                           const double* Ka, const double* Kd, const double* Ks,
+                           const int* map_Ka, const int* map_Kd, const int* map_Ks);
+/* Textures as tightly packed 8-bit RGB, top row first (what get_rgb reads through
+ * SDL_GetRGB, graphic_tools.c:161-197). */
+int rt_scene_set_textures(rt_scene* sc, int num_textures, const int* w, const int* h,
+                          const uint8_t* const* rgb);
+
+/* mat_mult.cu:8-28 on the device-resident master copy: eye = m * object for every vertex
+ * (slot 0 included, as driver.c:110 does), then the per-triangle fp32 sweep buffer
+ * (v0, e1, e2 planes) is rebuilt.  The object-space master is never overwritten, so no
+ * inverse pass (driver.c:202) is needed and no drift accumulates over frames. */
+int rt_scene_transform(rt_scene* sc, const double m[4][4]);
+/* Applies m to the master copy itself (what obj_reader.c:288 does at load time). */
+int rt_scene_bake(rt_scene* sc, const double m[4][4]);
+/* Copies the current eye-space vertices back (host, num_v+1 each). */
+int rt_scene_get_eye_vertices(rt_scene* sc, double* x, double* y, double* z);
+int rt_scene_num_tris(const rt_scene* sc);
+
+/* Primary rays of driver.c:121-135 for the pixel rows y_pix in [y0,y1): S = 0,
+ * E = (x_pix - W/2, y_pix - H/2, (W/2)/tan_half) with integer W/2, H/2.
+ * Outputs (device), indexed [(y_pix - y0)*W + x_pix]:
+ *   hit : int32 winning triangle or -1
+ *   tuv : 3 doubles per pixel (t,u,v), written only where hit != -1; may be NULL */
+int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int y0, int y1,
+                     int32_t* hit, double* tuv);
+
+/* n arbitrary rays, S and E as 3 doubles per ray (device).  Same outputs, plus point
+ * (3 doubles per ray, written on a hit; may be NULL).  intersect_all_triangles_device
+ * semantics per ray. */
+int rt_trace_rays(rt_scene* sc, int n, const double* S, const double* E,
+                  int32_t* hit, double* tuv, double* point);
+
+/* occ[i] = 1 if ray i hits any triangle at t > 0 (what light_model.c:70 asks), else 0. */
+int rt_occluded(rt_scene* sc, int n, const double* S, const double* E, uint8_t* occ);
+
+/* The whole pixel loop of driver.c:126-193 for rows [y0,y1): primary sweep, normal
+ * interpolation, material selection, Light_Model with its shadow rays, clamp.
+ * Outputs (device, any may be NULL), indexed [(y_pix - y0)*W + x_pix]:
+ *   hit  : int32      winning triangle or -1
+ *   tuv  : 3 doubles  t,u,v on a hit
+ *   argb : 3 doubles  the colour handed to set_rgb (driver.c:189)
+ *   rgb8 : 3 bytes    (Uint8)(c*255), graphic_tools.c:106-113 */
+int rt_render_rows(rt_scene* sc, const rt_frame* f, int W, int H, double tan_half,
+                   int y0, int y1, int32_t* hit, double* tuv, double* argb, uint8_t* rgb8);
+
+/* driver.c:186-190: rows [y0,y1) of rgb8 (as produced above) go to screen rows H - y_pix
+ * of a W*H*3 image whose row 0 keeps the clear colour (0,0,0) of driver.c:31-32; y_pix = 0
+ * falls off-screen.  Both pointers device.  The caller zeroes `screen` once per frame. */
+int rt_place_rows(const uint8_t* rgb8, int W, int H, int y0, int y1, uint8_t* screen);
+
+/* Row band of rank r out of n: contiguous, remainder to the last ranks one row each. */
+int rt_band(int H, int nranks, int rank, int* y0, int* y1);
+
+/* ------------------------------------------------------------------ measurement */
+typedef struct rt_profile {
+    double   sweep_ms;        /* sum of HIP-event durations of closest-hit sweep launches */
+    uint64_t sweep_launches;
+    uint64_t sweep_tests;     /* ray-triangle pairs those launches evaluated */
+    double   shadow_ms;       /* same for any-hit sweeps */
+    uint64_t shadow_launches;
+    uint64_t shadow_tests;    /* pairs actually evaluated (early-out accounted per tile) */
+    uint64_t rays_primary;
+    uint64_t rays_shadow;
+    uint64_t exact_candidates;  /* fp64 confirmations */
+    uint64_t exact_overflow;    /* rays that fell back to the full fp64 sweep */
+} rt_profile;
+int rt_profile_enable(int on);     /* wraps sweep launches in HIP events (adds a sync each) */
+int rt_profile_reset(void);
+int rt_profile_get(rt_profile* out);
+
+/* ------------------------------------------------------------------ host side (no GPU needed) */
+
+/* driver.c:34-107 for one frame: eye orbit of radius 15 at height 10, the two lights,
+ * RX(270 deg) object matrix. */
+int rt_driver_frame_setup(int frame_number, int frames_per_turn, rt_frame* out);
+/* M3d_matrix_tools.c:591-628, :305-471, :133-157, :163-178 */
+int rt_view(double view[4][4], double view_inverse[4][4],
+            const double eye[3], const double coi[3], const double up[3]);
+int rt_movement_sequence(double mat[4][4], double inv[4][4], int n,
+                         const int* types, const double* params);
+int rt_mat_mult(double res[4][4], const double a[4][4], const double b[4][4]);
+int rt_mat_mult_pt(double P[3], const double m[4][4], const double Q[3]);
+
+/* Wavefront .obj/.mtl loader with the reference's semantics (obj_reader.c:27-237,457-726):
+ * triangles and quads, four face formats, quads split (a,b,c)+(a,c,d), face normals
+ * synthesised when the file has none, centre + scale to a 15-unit box.  The result is
+ * structure-of-arrays in page-locked host memory when a GPU is present. */
+typedef struct rt_obj rt_obj;
+int rt_obj_load(const char* path, rt_obj** out);
+int rt_obj_free(rt_obj* o);
+typedef struct rt_obj_view {
+    int num_v, num_vn, num_vt, num_tris, num_mats;
+    const double *x, *y, *z;          /* num_v+1  */
+    const double *xn, *yn, *zn;       /* num_vn+1 */
+    const double *u, *v;              /* num_vt+1 */
+    const int *A, *B, *C, *An, *Bn, *Cn, *At, *Bt, *Ct, *mtl;   /* num_tris */
+    const double *Ka, *Kd, *Ks;       /* 3*num_mats */
+    const int *map_Ka, *map_Kd, *map_Ks;                        /* num_mats, -1 = none */
+    int pinned;                       /* 1 if the arrays are page-locked */
+} rt_obj_view;
+int rt_obj_get(const rt_obj* o, rt_obj_view* out);
+int rt_scene_set_obj(rt_scene* sc, const rt_obj* o);
+
+/* graphic_tools.c:19-23,115-121: 32-bit BMP with the ARGB8888 masks, alpha 0xFF, from a
+ * W*H*3 RGB screen image (host), top row first. */
+int rt_save_bmp(const char* path, const uint8_t* screen_rgb, int W, int H);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

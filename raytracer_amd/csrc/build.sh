@@ -1,0 +1,22 @@
+#!/bin/bash
+# Builds raytracer_amd/librt_amd.so for gfx950 (cross-compiles without a GPU).
+# -ffp-contract=off: every fp64 routine that mirrors reference arithmetic must round each
+# product and sum separately; the fp32 sweep spells its FMAs out with __builtin_fmaf.
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+root="$(cd "$here/../.." && pwd)"
+out="$root/raytracer_amd/librt_amd.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(-O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -I"$root/include" -I"$here" -Wall -Wno-unused-value)
+objs=()
+mkdir -p "$here/build"
+for src in rt_sweep.hip rt_exact.hip rt_transform.hip rt_shade.hip rt_api.hip rt_host.cpp rt_obj.cpp; do
+  obj="$here/build/${src%.*}.o"
+  if [ ! -f "$obj" ] || [ "$here/$src" -nt "$obj" ] || [ "$here/rt_internal.h" -nt "$obj" ] || [ "$root/include/rt_amd.h" -nt "$obj" ]; then
+    echo "hipcc $src"
+    "$HIPCC" "${FLAGS[@]}" ${EXTRA_FLAGS:-} -c "$here/$src" -o "$obj"
+  fi
+  objs+=("$obj")
+done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
+echo "built $out"

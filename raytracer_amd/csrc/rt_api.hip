@@ -1,0 +1,782 @@
+// rt_api.hip -- C ABI of the device path: library state, the device-resident scene, the
+// batched trace / render entry points and the reference's two kernel.h functions.
+#include "rt_internal.h"
+
+#include <cstdarg>
+#include <cmath>
+
+// ---------------------------------------------------------------- errors / state
+static thread_local char g_err[512] = "";
+
+void rt_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* rt_last_error(void) { return g_err; }
+extern "C" const char* rt_version(void) { return "rt_amd 0.1 (gfx950)"; }
+
+RtGlobal& rt_g()
+{
+    static RtGlobal g;
+    return g;
+}
+
+extern "C" int rt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int rt_init(int device_ordinal)
+{
+    RtGlobal& g = rt_g();
+    int n = rt_device_count();
+    if (n <= 0) {
+        rt_set_error("rt_init: no HIP device visible (this library has no CPU path)");
+        return RT_E_NODEVICE;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) {
+        rt_set_error("rt_init: device %d out of range [0,%d)", device_ordinal, n);
+        return RT_E_ARG;
+    }
+    RT_HIP(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    RT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        rt_set_error("rt_init: device %d is %s; this library is built for gfx950 only",
+                     device_ordinal, prop.gcnArchName);
+        return RT_E_NODEVICE;
+    }
+    if (!g.ev0) {
+        RT_HIP(hipEventCreate(&g.ev0));
+        RT_HIP(hipEventCreate(&g.ev1));
+    }
+    g.device = device_ordinal;
+    g.inited = true;
+    return RT_OK;
+}
+
+int rt_ensure_init()
+{
+    if (rt_g().inited) return RT_OK;
+    return rt_init(0);
+}
+
+extern "C" void rt_shutdown(void)
+{
+    RtGlobal& g = rt_g();
+    rt_legacy_invalidate();
+    if (g.ev0) { (void)hipEventDestroy(g.ev0); (void)hipEventDestroy(g.ev1); g.ev0 = g.ev1 = nullptr; }
+    g.inited = false;
+}
+
+extern "C" int rt_set_stream(void* hip_stream)
+{
+    rt_g().stream = static_cast<hipStream_t>(hip_stream);
+    return RT_OK;
+}
+
+extern "C" int rt_profile_enable(int on) { rt_g().profiling = on != 0; return RT_OK; }
+extern "C" int rt_profile_reset(void) { rt_g().prof = rt_profile{}; return RT_OK; }
+extern "C" int rt_profile_get(rt_profile* out)
+{
+    RT_ARG(out, "null output");
+    *out = rt_g().prof;
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------- DevBuf
+int DevBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap && p) return RT_OK;
+    if (bytes == 0) bytes = 16;
+    if (p) { RT_HIP(hipFree(p)); p = nullptr; cap = 0; }
+    RT_HIP(hipMalloc(&p, bytes));
+    cap = bytes;
+    return RT_OK;
+}
+
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+#define RT_TRY(expr)                    \
+    do {                                \
+        int rt_rc_ = (expr);            \
+        if (rt_rc_ != RT_OK) return rt_rc_; \
+    } while (0)
+
+static int upload(DevBuf& b, const void* host, size_t bytes)
+{
+    RT_TRY(b.reserve(bytes));
+    RT_HIP(hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, rt_g().stream));
+    RT_HIP(hipStreamSynchronize(rt_g().stream));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------- scene
+extern "C" int rt_scene_create(rt_scene** out)
+{
+    RT_ARG(out, "null output");
+    RT_TRY(rt_ensure_init());
+    *out = new rt_scene();
+    return RT_OK;
+}
+
+extern "C" int rt_scene_destroy(rt_scene* sc)
+{
+    if (!sc) return RT_OK;
+    DevBuf* bufs[] = {&sc->ox, &sc->oy, &sc->oz, &sc->ex, &sc->ey, &sc->ez, &sc->nx, &sc->ny, &sc->nz,
+                      &sc->tu, &sc->tv, &sc->iA, &sc->iB, &sc->iC, &sc->iAn, &sc->iBn, &sc->iCn,
+                      &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->pv0,
+                      &sc->pe1, &sc->pe2, &sc->scratch_max, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf,
+                      &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
+                      &sc->ws_occ, &sc->ws_shcnt, &sc->ws_shlist};
+    for (DevBuf* b : bufs) b->release();
+    for (DevBuf& b : sc->tex_data) b.release();
+    delete sc;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_num_tris(const rt_scene* sc) { return sc ? sc->num_tris : 0; }
+
+extern "C" int rt_scene_set_vertices(rt_scene* sc, int num_v, const double* x, const double* y,
+                                     const double* z)
+{
+    RT_ARG(sc && x && y && z, "null pointer");
+    RT_ARG(num_v >= 0, "negative vertex count");
+    const size_t bytes = sizeof(double) * (size_t)(num_v + 1);
+    RT_TRY(upload(sc->ox, x, bytes));
+    RT_TRY(upload(sc->oy, y, bytes));
+    RT_TRY(upload(sc->oz, z, bytes));
+    RT_TRY(sc->ex.reserve(bytes));
+    RT_TRY(sc->ey.reserve(bytes));
+    RT_TRY(sc->ez.reserve(bytes));
+    sc->num_v = num_v;
+    sc->transformed = false;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_normals(rt_scene* sc, int num_vn, const double* xn, const double* yn,
+                                    const double* zn)
+{
+    RT_ARG(sc && xn && yn && zn, "null pointer");
+    RT_ARG(num_vn >= 0, "negative normal count");
+    const size_t bytes = sizeof(double) * (size_t)(num_vn + 1);
+    RT_TRY(upload(sc->nx, xn, bytes));
+    RT_TRY(upload(sc->ny, yn, bytes));
+    RT_TRY(upload(sc->nz, zn, bytes));
+    sc->num_vn = num_vn;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_texcoords(rt_scene* sc, int num_vt, const double* u, const double* v)
+{
+    RT_ARG(sc && u && v, "null pointer");
+    RT_ARG(num_vt >= 0, "negative texture-vertex count");
+    const size_t bytes = sizeof(double) * (size_t)(num_vt + 1);
+    RT_TRY(upload(sc->tu, u, bytes));
+    RT_TRY(upload(sc->tv, v, bytes));
+    sc->num_vt = num_vt;
+    return RT_OK;
+}
+
+static bool in_range(const int* idx, int n, int lo, int hi)
+{
+    for (int i = 0; i < n; ++i)
+        if (idx[i] < lo || idx[i] > hi) return false;
+    return true;
+}
+
+extern "C" int rt_scene_set_triangles(rt_scene* sc, int num_tris, const int* A, const int* B,
+                                      const int* C, const int* An, const int* Bn, const int* Cn,
+                                      const int* At, const int* Bt, const int* Ct, const int* mtl)
+{
+    RT_ARG(sc && A && B && C, "null vertex index array");
+    RT_ARG(num_tris >= 0, "negative triangle count");
+    RT_ARG(in_range(A, num_tris, 0, sc->num_v) && in_range(B, num_tris, 0, sc->num_v) &&
+               in_range(C, num_tris, 0, sc->num_v),
+           "vertex index outside [0,num_v] (set vertices first)");
+    if (An || Bn || Cn) {
+        RT_ARG(An && Bn && Cn, "normal index arrays must come together");
+        RT_ARG(in_range(An, num_tris, 0, sc->num_vn) && in_range(Bn, num_tris, 0, sc->num_vn) &&
+                   in_range(Cn, num_tris, 0, sc->num_vn),
+               "normal index outside [0,num_vn] (set normals first)");
+    }
+    const bool tex = At && Bt && Ct;
+    if (tex)
+        RT_ARG(in_range(At, num_tris, 0, sc->num_vt) && in_range(Bt, num_tris, 0, sc->num_vt) &&
+                   in_range(Ct, num_tris, 0, sc->num_vt),
+               "texture index outside [0,num_vt] (set texcoords first)");
+    const size_t bytes = sizeof(int) * (size_t)(num_tris > 0 ? num_tris : 1);
+    RT_TRY(upload(sc->iA, A, sizeof(int) * (size_t)num_tris));
+    RT_TRY(upload(sc->iB, B, sizeof(int) * (size_t)num_tris));
+    RT_TRY(upload(sc->iC, C, sizeof(int) * (size_t)num_tris));
+    if (An) {
+        RT_TRY(upload(sc->iAn, An, sizeof(int) * (size_t)num_tris));
+        RT_TRY(upload(sc->iBn, Bn, sizeof(int) * (size_t)num_tris));
+        RT_TRY(upload(sc->iCn, Cn, sizeof(int) * (size_t)num_tris));
+    } else {
+        sc->iAn.release(); sc->iBn.release(); sc->iCn.release();
+    }
+    if (tex) {
+        RT_TRY(upload(sc->iAt, At, sizeof(int) * (size_t)num_tris));
+        RT_TRY(upload(sc->iBt, Bt, sizeof(int) * (size_t)num_tris));
+        RT_TRY(upload(sc->iCt, Ct, sizeof(int) * (size_t)num_tris));
+    }
+    sc->has_tex_idx = tex;
+    if (mtl) {
+        RT_TRY(upload(sc->imtl, mtl, sizeof(int) * (size_t)num_tris));
+    } else {
+        sc->imtl.release();
+    }
+    (void)bytes;
+    sc->num_tris = num_tris;
+    sc->num_tris_padded = ((num_tris + RT_TILE - 1) / RT_TILE) * RT_TILE;
+    if (sc->num_tris_padded == 0) sc->num_tris_padded = RT_TILE;
+    const size_t pb = sizeof(float4) * (size_t)sc->num_tris_padded;
+    RT_TRY(sc->pv0.reserve(pb));
+    RT_TRY(sc->pe1.reserve(pb));
+    RT_TRY(sc->pe2.reserve(pb));
+    RT_TRY(sc->scratch_max.reserve(16));
+    sc->transformed = false;
+    return RT_OK;
+}
+
+static int g_tri_stride = 0;
+extern "C" void rt_set_triangle_stride(int bytes) { g_tri_stride = bytes; }
+
+// Splits the reference's array-of-structures into index arrays (host side).
+static void split_aos(const Triangle* tris, int n, std::vector<int> idx[9], std::vector<int>& mtl)
+{
+    const size_t stride = g_tri_stride > 0 ? (size_t)g_tri_stride : sizeof(Triangle);
+    for (int k = 0; k < 9; ++k) idx[k].resize(n);
+    mtl.resize(n);
+    const char* base = reinterpret_cast<const char*>(tris);
+    for (int i = 0; i < n; ++i) {
+        const Triangle* t = reinterpret_cast<const Triangle*>(base + stride * (size_t)i);
+        idx[0][i] = t->A;  idx[1][i] = t->B;  idx[2][i] = t->C;
+        idx[3][i] = t->An; idx[4][i] = t->Bn; idx[5][i] = t->Cn;
+        idx[6][i] = t->At; idx[7][i] = t->Bt; idx[8][i] = t->Ct;
+        mtl[i] = t->mtl.index;
+    }
+}
+
+extern "C" int rt_scene_set_triangles_aos(rt_scene* sc, const Triangle* tris, int num_tris)
+{
+    RT_ARG(sc && tris, "null pointer");
+    RT_ARG(num_tris >= 0, "negative triangle count");
+    std::vector<int> idx[9], mtl;
+    split_aos(tris, num_tris, idx, mtl);
+    // texture indices are uninitialised in the reference for faces without vt
+    // (obj_reader.c:96-104,145-160): only pass them on when every one is in range.
+    const bool tex = sc->num_vt > 0 && in_range(idx[6].data(), num_tris, 0, sc->num_vt) &&
+                     in_range(idx[7].data(), num_tris, 0, sc->num_vt) &&
+                     in_range(idx[8].data(), num_tris, 0, sc->num_vt);
+    int max_m = -1;
+    for (int i = 0; i < num_tris; ++i) max_m = mtl[i] > max_m ? mtl[i] : max_m;
+    if (max_m >= 0) {
+        // rebuild the material table from the per-triangle copies (obj_reader.c:84-90)
+        const size_t stride = g_tri_stride > 0 ? (size_t)g_tri_stride : sizeof(Triangle);
+        std::vector<double> Ka(3 * (max_m + 1), 1.0), Kd(3 * (max_m + 1), 1.0), Ks(3 * (max_m + 1), 1.0);
+        const char* base = reinterpret_cast<const char*>(tris);
+        for (int i = 0; i < num_tris; ++i) {
+            if (mtl[i] < 0) continue;
+            const Triangle* t = reinterpret_cast<const Triangle*>(base + stride * (size_t)i);
+            for (int k = 0; k < 3; ++k) {
+                Ka[3 * mtl[i] + k] = t->mtl.Ka[k];
+                Kd[3 * mtl[i] + k] = t->mtl.Kd[k];
+                Ks[3 * mtl[i] + k] = t->mtl.Ks[k];
+            }
+        }
+        RT_TRY(rt_scene_set_materials(sc, max_m + 1, Ka.data(), Kd.data(), Ks.data(), nullptr,
+                                      nullptr, nullptr));
+    }
+    return rt_scene_set_triangles(sc, num_tris, idx[0].data(), idx[1].data(), idx[2].data(),
+                                  idx[3].data(), idx[4].data(), idx[5].data(),
+                                  tex ? idx[6].data() : nullptr, tex ? idx[7].data() : nullptr,
+                                  tex ? idx[8].data() : nullptr, mtl.data());
+}
+
+extern "C" int rt_scene_set_materials(rt_scene* sc, int num_mats, const double* Ka, const double* Kd,
+                                      const double* Ks, const int* map_Ka, const int* map_Kd,
+                                      const int* map_Ks)
+{
+    RT_ARG(sc, "null scene");
+    RT_ARG(num_mats >= 0, "negative material count");
+    RT_ARG(num_mats == 0 || (Ka && Kd && Ks), "null colour array");
+    std::vector<DevMaterial> m((size_t)num_mats);
+    for (int i = 0; i < num_mats; ++i) {
+        for (int k = 0; k < 3; ++k) {
+            m[i].Ka[k] = Ka[3 * i + k];
+            m[i].Kd[k] = Kd[3 * i + k];
+            m[i].Ks[k] = Ks[3 * i + k];
+        }
+        m[i].map_Ka = map_Ka ? map_Ka[i] : -1;
+        m[i].map_Kd = map_Kd ? map_Kd[i] : -1;
+        m[i].map_Ks = map_Ks ? map_Ks[i] : -1;
+        m[i].pad = 0;
+    }
+    if (num_mats > 0) RT_TRY(upload(sc->mats, m.data(), sizeof(DevMaterial) * (size_t)num_mats));
+    sc->num_mats = num_mats;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_textures(rt_scene* sc, int num_textures, const int* w, const int* h,
+                                     const uint8_t* const* rgb)
+{
+    RT_ARG(sc, "null scene");
+    RT_ARG(num_textures >= 0, "negative texture count");
+    RT_ARG(num_textures == 0 || (w && h && rgb), "null pointer");
+    for (DevBuf& b : sc->tex_data) b.release();
+    sc->tex_data.assign((size_t)num_textures, DevBuf());
+    std::vector<DevTexture> d((size_t)num_textures);
+    for (int i = 0; i < num_textures; ++i) {
+        RT_ARG(w[i] > 0 && h[i] > 0 && rgb[i], "bad texture");
+        RT_TRY(upload(sc->tex_data[i], rgb[i], (size_t)w[i] * h[i] * 3));
+        d[i].rgb = sc->tex_data[i].as<uint8_t>();
+        d[i].w = w[i];
+        d[i].h = h[i];
+    }
+    if (num_textures > 0) RT_TRY(upload(sc->tex_desc, d.data(), sizeof(DevTexture) * d.size()));
+    sc->num_tex = num_textures;
+    return RT_OK;
+}
+
+static int transform_into(rt_scene* sc, const double m[4][4], bool bake)
+{
+    RT_ARG(sc && m, "null pointer");
+    if (!sc->ox.p) {
+        rt_set_error("transform: no vertices set");
+        return RT_E_STATE;
+    }
+    hipStream_t st = rt_g().stream;
+    DevBuf mdev;    // 128 B; tiny and rare enough for a temporary
+    RT_TRY(mdev.reserve(16 * sizeof(double)));
+    int rc = RT_OK;
+    do {
+        if (hipMemcpyAsync(mdev.p, m, 16 * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
+            rt_set_error("transform: matrix upload failed");
+            rc = RT_E_HIP;
+            break;
+        }
+        const int n = sc->num_v + 1;
+        if (bake) {
+            rc = rt_launch_transform(mdev.as<double>(), sc->ox.as<double>(), sc->oy.as<double>(),
+                                     sc->oz.as<double>(), sc->ox.as<double>(), sc->oy.as<double>(),
+                                     sc->oz.as<double>(), n, nullptr, st);
+            sc->transformed = false;
+        } else {
+            if (!sc->iA.p || !sc->scratch_max.p) {
+                rt_set_error("transform: no triangles set");
+                rc = RT_E_STATE;
+                break;
+            }
+            if (hipMemsetAsync(sc->scratch_max.p, 0, 4, st) != hipSuccess) { rc = RT_E_HIP; break; }
+            rc = rt_launch_transform(mdev.as<double>(), sc->ox.as<double>(), sc->oy.as<double>(),
+                                     sc->oz.as<double>(), sc->ex.as<double>(), sc->ey.as<double>(),
+                                     sc->ez.as<double>(), n, sc->scratch_max.as<unsigned>(), st);
+            if (rc) break;
+            rc = rt_launch_pack(sc, st);
+            if (rc) break;
+            sc->transformed = true;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) {
+            rt_set_error("transform: kernel failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = RT_E_HIP;
+        }
+    } while (0);
+    mdev.release();
+    return rc;
+}
+
+extern "C" int rt_scene_transform(rt_scene* sc, const double m[4][4]) { return transform_into(sc, m, false); }
+extern "C" int rt_scene_bake(rt_scene* sc, const double m[4][4]) { return transform_into(sc, m, true); }
+
+extern "C" int rt_scene_get_eye_vertices(rt_scene* sc, double* x, double* y, double* z)
+{
+    RT_ARG(sc && x && y && z, "null pointer");
+    if (!sc->transformed) {
+        rt_set_error("get_eye_vertices: scene not transformed");
+        return RT_E_STATE;
+    }
+    const size_t bytes = sizeof(double) * (size_t)(sc->num_v + 1);
+    RT_HIP(hipMemcpy(x, sc->ex.p, bytes, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(y, sc->ey.p, bytes, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(z, sc->ez.p, bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------- tracing
+static ExactScene exact_of(const rt_scene* sc)
+{
+    ExactScene es;
+    es.x = sc->ex.as<double>(); es.y = sc->ey.as<double>(); es.z = sc->ez.as<double>();
+    es.A = sc->iA.as<int>(); es.B = sc->iB.as<int>(); es.C = sc->iC.as<int>();
+    es.num_tris = sc->num_tris;
+    return es;
+}
+
+static int require_ready(const rt_scene* sc)
+{
+    if (!sc) { rt_set_error("null scene"); return RT_E_ARG; }
+    if (!sc->transformed) {
+        rt_set_error("scene has no eye-space geometry: call rt_scene_transform first");
+        return RT_E_STATE;
+    }
+    return RT_OK;
+}
+
+// Runs a sweep launch, optionally bracketed by HIP events on the launch stream.
+template <class F>
+static int timed_sweep(F&& launch, bool shadow, uint64_t tests_if_closest,
+                       unsigned long long* dev_tests)
+{
+    RtGlobal& g = rt_g();
+    if (!g.profiling) return launch();
+    RT_HIP(hipEventRecord(g.ev0, g.stream));
+    int rc = launch();
+    if (rc) return rc;
+    RT_HIP(hipEventRecord(g.ev1, g.stream));
+    RT_HIP(hipEventSynchronize(g.ev1));
+    float ms = 0;
+    RT_HIP(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+    if (shadow) {
+        unsigned long long t = 0;
+        RT_HIP(hipMemcpy(&t, dev_tests, sizeof t, hipMemcpyDeviceToHost));
+        g.prof.shadow_ms += ms; g.prof.shadow_launches++; g.prof.shadow_tests += t;
+    } else {
+        g.prof.sweep_ms += ms; g.prof.sweep_launches++; g.prof.sweep_tests += tests_if_closest;
+    }
+    return RT_OK;
+}
+
+static int workspaces(rt_scene* sc, size_t slots)
+{
+    RT_TRY(sc->ws_cnt.reserve(sizeof(int32_t) * slots));
+    RT_TRY(sc->ws_list.reserve(sizeof(int32_t) * slots * RT_LIST_K));
+    RT_TRY(sc->ws_ovf.reserve(sizeof(int32_t) * slots));
+    RT_TRY(sc->ws_counters.reserve(64));
+    return RT_OK;
+}
+
+static int fetch_counters(rt_scene* sc, bool sync_always)
+{
+    // counters[0] = overflowed rays, [1] = fp64 candidates evaluated, [2..3] = pair counter
+    RtGlobal& g = rt_g();
+    if (!g.profiling && !sync_always) return RT_OK;
+    int c[4] = {0, 0, 0, 0};
+    RT_HIP(hipMemcpyAsync(c, sc->ws_counters.p, sizeof c, hipMemcpyDeviceToHost, g.stream));
+    RT_HIP(hipStreamSynchronize(g.stream));
+    g.prof.exact_overflow += (uint64_t)c[0];
+    g.prof.exact_candidates += (uint64_t)c[1];
+    return RT_OK;
+}
+
+extern "C" int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int y0, int y1,
+                                int32_t* hit, double* tuv)
+{
+    RT_TRY(require_ready(sc));
+    RT_ARG(hit, "null hit buffer");
+    RT_ARG(W > 0 && H > 0 && y0 >= 0 && y1 <= H && y0 < y1, "bad image size or row band");
+    RT_ARG(tan_half > 0, "tan_half must be positive");
+    RtGlobal& g = rt_g();
+    hipStream_t st = g.stream;
+    const size_t npix = (size_t)W * (y1 - y0);
+    RT_TRY(workspaces(sc, npix));
+    RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
+
+    SweepArgs a{};
+    a.v0 = sc->pv0.as<float4>(); a.e1 = sc->pe1.as<float4>(); a.e2 = sc->pe2.as<float4>();
+    a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
+    a.W = W; a.H = H; a.y0 = y0; a.y1 = y1;
+    a.ez = (double)(W / 2) / tan_half;
+    a.cnt = sc->ws_cnt.as<int32_t>(); a.list = sc->ws_list.as<int32_t>();
+    a.tests = nullptr;
+    const int tiles_x = (W + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (y1 - y0 + RT_TILE_H - 1) / RT_TILE_H;
+    const uint64_t tests = (uint64_t)tiles_x * tiles_y * RT_RAYS_PER_WG * (uint64_t)sc->num_tris_padded;
+    RT_TRY(timed_sweep([&] { return rt_launch_sweep_primary(a, st); }, false, tests, nullptr));
+    g.prof.rays_primary += npix;
+
+    const ExactScene es = exact_of(sc);
+    int* counters = sc->ws_counters.as<int>();
+    RT_TRY(rt_launch_resolve_primary(es, W, H, tan_half, y0, y1, a.cnt, a.list, hit, tuv,
+                                     sc->ws_ovf.as<int32_t>(), counters, st));
+    RT_TRY(rt_launch_overflow_primary(es, W, H, tan_half, y0, sc->ws_ovf.as<int32_t>(), counters,
+                                      hit, tuv, st));
+    RT_TRY(fetch_counters(sc, false));
+    RT_HIP(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E, bool anyhit,
+                           int tiledW, int y0, int y1, int32_t* hit, double* tuv, double* point,
+                           uint8_t* occ)
+{
+    RtGlobal& g = rt_g();
+    hipStream_t st = g.stream;
+    if (n == 0) return RT_OK;
+    RT_TRY(workspaces(sc, (size_t)n));
+    RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
+    SweepArgs a{};
+    a.v0 = sc->pv0.as<float4>(); a.e1 = sc->pe1.as<float4>(); a.e2 = sc->pe2.as<float4>();
+    a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
+    a.W = tiledW; a.y0 = y0; a.y1 = y1; a.H = 0;
+    a.n_rays = n; a.S = S; a.E = E;
+    a.cnt = sc->ws_cnt.as<int32_t>(); a.list = sc->ws_list.as<int32_t>();
+    a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
+    const uint64_t wgs = tiledW > 0
+        ? (uint64_t)((tiledW + RT_TILE_W - 1) / RT_TILE_W) * ((y1 - y0 + RT_TILE_H - 1) / RT_TILE_H) *
+              (uint64_t)(n / ((size_t)tiledW * (y1 - y0)))
+        : (uint64_t)((n + RT_RAYS_PER_WG - 1) / RT_RAYS_PER_WG);
+    const uint64_t tests = wgs * RT_RAYS_PER_WG * (uint64_t)sc->num_tris_padded;
+    RT_TRY(timed_sweep([&] { return rt_launch_sweep_rays(a, anyhit, st); }, anyhit, tests, a.tests));
+    if (anyhit) g.prof.rays_shadow += (uint64_t)n;
+    else g.prof.rays_primary += (uint64_t)n;
+    const ExactScene es = exact_of(sc);
+    int* counters = sc->ws_counters.as<int>();
+    RT_TRY(rt_launch_resolve_rays(es, n, S, E, a.cnt, a.list, anyhit, hit, tuv, point, occ,
+                                  sc->ws_ovf.as<int32_t>(), counters, st));
+    RT_TRY(rt_launch_overflow_rays(es, S, E, sc->ws_ovf.as<int32_t>(), counters, anyhit, hit, tuv,
+                                   point, occ, st));
+    RT_TRY(fetch_counters(sc, false));
+    return RT_OK;
+}
+
+extern "C" int rt_trace_rays(rt_scene* sc, int n, const double* S, const double* E, int32_t* hit,
+                             double* tuv, double* point)
+{
+    RT_TRY(require_ready(sc));
+    RT_ARG(n >= 0, "negative ray count");
+    RT_ARG(n == 0 || (S && E && hit), "null pointer");
+    RT_TRY(trace_rays_impl(sc, n, S, E, false, 0, 0, 0, hit, tuv, point, nullptr));
+    RT_HIP(hipStreamSynchronize(rt_g().stream));
+    return RT_OK;
+}
+
+extern "C" int rt_occluded(rt_scene* sc, int n, const double* S, const double* E, uint8_t* occ)
+{
+    RT_TRY(require_ready(sc));
+    RT_ARG(n >= 0, "negative ray count");
+    RT_ARG(n == 0 || (S && E && occ), "null pointer");
+    RT_TRY(trace_rays_impl(sc, n, S, E, true, 0, 0, 0, nullptr, nullptr, nullptr, occ));
+    RT_HIP(hipStreamSynchronize(rt_g().stream));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------- whole pixel loop
+extern "C" int rt_render_rows(rt_scene* sc, const rt_frame* f, int W, int H, double tan_half,
+                              int y0, int y1, int32_t* hit, double* tuv, double* argb,
+                              uint8_t* rgb8)
+{
+    RT_TRY(require_ready(sc));
+    RT_ARG(f, "null frame");
+    RT_ARG(f->num_lights >= 0 && f->num_lights <= RT_MAX_LIGHTS, "num_lights outside [0,100]");
+    RT_ARG(W > 0 && H > 0 && y0 >= 0 && y1 <= H && y0 < y1, "bad image size or row band");
+    RT_ARG(sc->iAn.p && sc->nx.p, "scene has no normals (needed for shading)");
+    RtGlobal& g = rt_g();
+    hipStream_t st = g.stream;
+    const size_t npix = (size_t)W * (y1 - y0);
+    const int L = f->num_lights;
+
+    if (!hit) { RT_TRY(sc->ws_hit.reserve(sizeof(int32_t) * npix)); hit = sc->ws_hit.as<int32_t>(); }
+    if (!tuv) { RT_TRY(sc->ws_tuv.reserve(sizeof(double) * 3 * npix)); tuv = sc->ws_tuv.as<double>(); }
+    RT_TRY(rt_trace_primary(sc, W, H, tan_half, y0, y1, hit, tuv));
+
+    // frame constants
+    static DevBuf frame_dev;
+    RT_TRY(frame_dev.reserve(sizeof(DevFrame)));
+    static DevFrame hf;     // static: outlives the async copy below
+    hf.num_lights = L;
+    memcpy(hf.obinv, f->obinv, sizeof hf.obinv);
+    memcpy(hf.light_pos, f->light_in_eye_space, sizeof hf.light_pos);
+    memcpy(hf.light_rgb, f->light_rgb, sizeof hf.light_rgb);
+    memcpy(hf.light_att, f->light_attenuation, sizeof hf.light_att);
+    memcpy(hf.light_max, f->light_max_dist, sizeof hf.light_max);
+    RT_HIP(hipMemcpyAsync(frame_dev.p, &hf, sizeof hf, hipMemcpyHostToDevice, st));
+    RT_HIP(hipStreamSynchronize(st));
+
+    ShadeArgs a{};
+    a.es = exact_of(sc);
+    a.An = sc->iAn.as<int>(); a.Bn = sc->iBn.as<int>(); a.Cn = sc->iCn.as<int>();
+    a.At = sc->has_tex_idx ? sc->iAt.as<int>() : nullptr;
+    a.Bt = sc->has_tex_idx ? sc->iBt.as<int>() : nullptr;
+    a.Ct = sc->has_tex_idx ? sc->iCt.as<int>() : nullptr;
+    a.mtl = sc->imtl.p ? sc->imtl.as<int>() : nullptr;
+    a.nx = sc->nx.as<double>(); a.ny = sc->ny.as<double>(); a.nz = sc->nz.as<double>();
+    a.tu = sc->tu.as<double>(); a.tv = sc->tv.as<double>();
+    a.mats = sc->mats.as<DevMaterial>(); a.tex = sc->tex_desc.as<DevTexture>();
+    a.num_mats = sc->num_mats;
+    a.frame = frame_dev.as<DevFrame>();
+    a.num_lights = L;
+    a.W = W; a.H = H; a.y0 = y0; a.y1 = y1; a.tan_half = tan_half;
+    a.hit = hit; a.tuv = tuv;
+    a.argb = argb; a.rgb8 = rgb8;
+    if (L > 0) {
+        const size_t nsh = npix * (size_t)L;
+        RT_ARG(nsh < (size_t)1 << 31, "band * lights exceeds 2^31 shadow rays; render fewer rows per call");
+        RT_TRY(sc->ws_shS.reserve(sizeof(double) * 3 * nsh));
+        RT_TRY(sc->ws_shE.reserve(sizeof(double) * 3 * nsh));
+        RT_TRY(sc->ws_occ.reserve(nsh));
+        a.shS = sc->ws_shS.as<double>(); a.shE = sc->ws_shE.as<double>();
+        a.occ = sc->ws_occ.as<uint8_t>();
+        RT_TRY(rt_launch_shadow_setup(a, st));
+        RT_TRY(trace_rays_impl(sc, (int)nsh, a.shS, a.shE, true, W, y0, y1, nullptr, nullptr,
+                               nullptr, sc->ws_occ.as<uint8_t>()));
+    }
+    RT_TRY(rt_launch_shade_final(a, st));
+    RT_HIP(hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+extern "C" int rt_place_rows(const uint8_t* rgb8, int W, int H, int y0, int y1, uint8_t* screen)
+{
+    RT_ARG(rgb8 && screen, "null pointer");
+    RT_ARG(W > 0 && H > 0 && y0 >= 0 && y1 <= H && y0 <= y1, "bad image size or row band");
+    RT_TRY(rt_ensure_init());
+    RT_TRY(rt_launch_place_rows(rgb8, W, H, y0, y1, screen, rt_g().stream));
+    RT_HIP(hipStreamSynchronize(rt_g().stream));
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------- the reference's kernel.h API
+namespace {
+
+struct LegacyState {
+    DevBuf m, x, y, z;                 // mat_mult_device staging
+    // cached mesh of intersect_all_triangles_device
+    const void* tris_host = nullptr;
+    const double *xh = nullptr, *yh = nullptr, *zh = nullptr;
+    int num_tris = -1, num_pts = 0;
+    bool valid = false;
+    DevBuf iA, iB, iC, mx, my, mz, io;   // io: S,E in / result + partials out
+};
+LegacyState& legacy()
+{
+    static LegacyState s;
+    return s;
+}
+
+bool overlaps(const double* a, size_t na, const double* b, size_t nb)
+{
+    if (!a || !b) return false;
+    const char* a0 = reinterpret_cast<const char*>(a);
+    const char* b0 = reinterpret_cast<const char*>(b);
+    return a0 < b0 + nb * sizeof(double) && b0 < a0 + na * sizeof(double);
+}
+
+void legacy_fail(const char* what)
+{
+    // The reference API has no error channel (kernel.h:10-17).  A device failure here must
+    // not pass silently as a plausible result, so it is reported and the call is fatal.
+    fprintf(stderr, "rt_amd: %s: %s\n", what, rt_last_error());
+    abort();
+}
+
+}  // namespace
+
+extern "C" void rt_legacy_invalidate(void) { legacy().valid = false; }
+
+extern "C" void mat_mult_device(double* X, double* Y, double* Z, double m[4][4], double* x,
+                                double* y, double* z, int numpoints)
+{
+    if (numpoints <= 0) return;
+    if (rt_ensure_init() != RT_OK) legacy_fail("mat_mult_device");
+    LegacyState& s = legacy();
+    hipStream_t st = rt_g().stream;
+    const size_t bytes = sizeof(double) * (size_t)numpoints;
+    auto ok = [&](hipError_t e) {
+        if (e != hipSuccess) {
+            rt_set_error("%s", hipGetErrorString(e));
+            legacy_fail("mat_mult_device");
+        }
+    };
+    if (s.m.reserve(128) || s.x.reserve(bytes) || s.y.reserve(bytes) || s.z.reserve(bytes))
+        legacy_fail("mat_mult_device");
+    ok(hipMemcpyAsync(s.m.p, m, 128, hipMemcpyHostToDevice, st));
+    ok(hipMemcpyAsync(s.x.p, x, bytes, hipMemcpyHostToDevice, st));
+    ok(hipMemcpyAsync(s.y.p, y, bytes, hipMemcpyHostToDevice, st));
+    ok(hipMemcpyAsync(s.z.p, z, bytes, hipMemcpyHostToDevice, st));
+    if (rt_launch_transform(s.m.as<double>(), s.x.as<double>(), s.y.as<double>(), s.z.as<double>(),
+                            s.x.as<double>(), s.y.as<double>(), s.z.as<double>(), numpoints, nullptr,
+                            st) != RT_OK)
+        legacy_fail("mat_mult_device");
+    ok(hipMemcpyAsync(X, s.x.p, bytes, hipMemcpyDeviceToHost, st));
+    ok(hipMemcpyAsync(Y, s.y.p, bytes, hipMemcpyDeviceToHost, st));
+    ok(hipMemcpyAsync(Z, s.z.p, bytes, hipMemcpyDeviceToHost, st));
+    ok(hipStreamSynchronize(st));
+    // the vertex arrays behind the cached mesh were rewritten (driver.c:110,202)
+    if (s.valid && (overlaps(X, numpoints, s.xh, s.num_pts) || overlaps(Y, numpoints, s.yh, s.num_pts) ||
+                    overlaps(Z, numpoints, s.zh, s.num_pts)))
+        s.valid = false;
+}
+
+extern "C" int intersect_all_triangles_device(double S[3], double E[3], double uv[2],
+                                              double point[3], Triangle* tris, double* x, double* y,
+                                              double* z, int num_tris)
+{
+    if (num_tris <= 0) return -1;
+    if (rt_ensure_init() != RT_OK) legacy_fail("intersect_all_triangles_device");
+    LegacyState& s = legacy();
+    hipStream_t st = rt_g().stream;
+    auto ok = [&](hipError_t e) {
+        if (e != hipSuccess) {
+            rt_set_error("%s", hipGetErrorString(e));
+            legacy_fail("intersect_all_triangles_device");
+        }
+    };
+    if (!s.valid || s.tris_host != tris || s.xh != x || s.yh != y || s.zh != z || s.num_tris != num_tris) {
+        // (re)build the device copy.  The API carries no vertex count (kernel.h:16-17); the
+        // arrays must reach at least the largest index any triangle uses.
+        std::vector<int> idx[9], mtl;
+        split_aos(tris, num_tris, idx, mtl);
+        int maxi = 0;
+        for (int k = 0; k < 3; ++k)
+            for (int i = 0; i < num_tris; ++i) {
+                if (idx[k][i] < 0) {
+                    rt_set_error("negative vertex index in triangle %d", i);
+                    legacy_fail("intersect_all_triangles_device");
+                }
+                maxi = idx[k][i] > maxi ? idx[k][i] : maxi;
+            }
+        const size_t ib = sizeof(int) * (size_t)num_tris, vb = sizeof(double) * (size_t)(maxi + 1);
+        if (s.iA.reserve(ib) || s.iB.reserve(ib) || s.iC.reserve(ib) || s.mx.reserve(vb) ||
+            s.my.reserve(vb) || s.mz.reserve(vb) || s.io.reserve(64 + 64 + 32 * 256))
+            legacy_fail("intersect_all_triangles_device");
+        ok(hipMemcpyAsync(s.iA.p, idx[0].data(), ib, hipMemcpyHostToDevice, st));
+        ok(hipMemcpyAsync(s.iB.p, idx[1].data(), ib, hipMemcpyHostToDevice, st));
+        ok(hipMemcpyAsync(s.iC.p, idx[2].data(), ib, hipMemcpyHostToDevice, st));
+        ok(hipMemcpyAsync(s.mx.p, x, vb, hipMemcpyHostToDevice, st));
+        ok(hipMemcpyAsync(s.my.p, y, vb, hipMemcpyHostToDevice, st));
+        ok(hipMemcpyAsync(s.mz.p, z, vb, hipMemcpyHostToDevice, st));
+        ok(hipStreamSynchronize(st));      // idx[] vectors die at the end of this block
+        s.tris_host = tris; s.xh = x; s.yh = y; s.zh = z;
+        s.num_tris = num_tris; s.num_pts = maxi + 1;
+        s.valid = true;
+    }
+    double se[6] = {S[0], S[1], S[2], E[0], E[1], E[2]};
+    double* io = s.io.as<double>();
+    ok(hipMemcpyAsync(io, se, sizeof se, hipMemcpyHostToDevice, st));
+    ExactScene es;
+    es.x = s.mx.as<double>(); es.y = s.my.as<double>(); es.z = s.mz.as<double>();
+    es.A = s.iA.as<int>(); es.B = s.iB.as<int>(); es.C = s.iC.as<int>();
+    es.num_tris = num_tris;
+    if (rt_launch_single_ray(es, io, io + 8, st) != RT_OK) legacy_fail("intersect_all_triangles_device");
+    double out[7];
+    ok(hipMemcpyAsync(out, io + 8, sizeof out, hipMemcpyDeviceToHost, st));
+    ok(hipStreamSynchronize(st));
+    const int closest = (int)out[0];
+    if (closest != -1) {
+        uv[0] = out[2]; uv[1] = out[3];
+        point[0] = out[4]; point[1] = out[5]; point[2] = out[6];
+    }
+    return closest;
+}

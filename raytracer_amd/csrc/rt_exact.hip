@@ -1,0 +1,402 @@
+// rt_exact.hip -- fp64 evaluation with the reference's exact arithmetic and comparison rules.
+//
+// This translation unit is compiled with -ffp-contract=off: every product and sum below is
+// rounded separately, in the statement order of triangle_intersection.cu:13-29,59-95, so
+// that t, u, v and every accept/reject decision are those of the reference's formulas in
+// strict IEEE binary64 (fp64 division and square root are correctly rounded on gfx950).
+//
+// Three users:
+//   * the confirmation pass behind the fp32 sweep (rt_sweep.hip): a handful of candidate
+//     triangles per ray, in ascending index order, reduced with the host loop's rule
+//     `dist > 0 && dist < t` (triangle_intersection.cu:167-176: strict '<', lowest index
+//     wins a tie);
+//   * the fallback for rays whose candidate list overflowed: a full sweep, one workgroup
+//     per ray, threads striding over triangles -- the reference's own parallel axis;
+//   * intersect_all_triangles_device, the reference's one-ray API.
+#include "rt_internal.h"
+
+namespace {
+
+constexpr int OCC_BIT = 0x40000000;
+
+// triangle_intersection.cu:6-11
+__device__ __forceinline__ double det_2x2(double a0, double a1, double b0, double b1)
+{
+    return a0 * b1 - a1 * b0;
+}
+
+// triangle_intersection.cu:13-29: 0 + A0*|B1 C1;B2 C2| + (-B0)*|A1 C1;A2 C2| + C0*|A1 B1;A2 B2|
+__device__ __forceinline__ double det_3x3(const double A[3], const double B[3], const double C[3])
+{
+    double det = 0;
+    det += A[0] * det_2x2(B[1], B[2], C[1], C[2]);
+    det += -B[0] * det_2x2(A[1], A[2], C[1], C[2]);
+    det += C[0] * det_2x2(A[1], A[2], B[1], B[2]);
+    return det;
+}
+
+// triangle_intersection.cu:59-95 for one triangle.  Returns dist (t or -1).
+__device__ __forceinline__ double exact_single(const double S[3], const double E[3],
+                                               const double A[3], const double B[3],
+                                               const double C[3], double& u, double& v)
+{
+    double AB[3], AC[3], ES[3], AS[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        AB[k] = B[k] - A[k];
+        AC[k] = C[k] - A[k];
+        ES[k] = S[k] - E[k];
+        AS[k] = S[k] - A[k];
+    }
+    const double den = det_3x3(AB, AC, ES);
+    if (den == 0) return -1;
+    const double t = det_3x3(AB, AC, AS) / den;
+    if (t < 0) return -1;
+    u = det_3x3(AS, AC, ES) / den;
+    if ((u < 0) || (u > 1)) return -1;
+    v = det_3x3(AB, AS, ES) / den;
+    if ((v < 0) || (v > 1)) return -1;
+    if (u + v > 1) return -1;
+    return t;
+}
+
+__device__ __forceinline__ double exact_tri(const ExactScene& es, int i, const double S[3],
+                                            const double E[3], double& u, double& v)
+{
+    const int a = es.A[i], b = es.B[i], c = es.C[i];
+    const double A[3] = {es.x[a], es.y[a], es.z[a]};
+    const double B[3] = {es.x[b], es.y[b], es.z[b]};
+    const double C[3] = {es.x[c], es.y[c], es.z[c]};
+    return exact_single(S, E, A, B, C, u, v);
+}
+
+// driver.c:121-133
+__device__ __forceinline__ void primary_ray(int W, int H, double tan_half, int px, int py,
+                                            double S[3], double E[3])
+{
+    S[0] = S[1] = S[2] = 0;
+    E[0] = (double)(px - W / 2);
+    E[1] = (double)(py - H / 2);
+    E[2] = (double)(W / 2) / tan_half;
+}
+
+struct Best {
+    double t, u, v;
+    int idx;
+};
+
+// Confirmation of one ray's candidate list.  Returns false when the list overflowed.
+template <bool ANYHIT>
+__device__ __forceinline__ bool confirm_list(const ExactScene& es, const double S[3],
+                                             const double E[3], int cnt,
+                                             const int32_t* __restrict__ list, Best& best,
+                                             bool& occluded)
+{
+    best.t = 1e50;                  // triangle_intersection.cu:108
+    best.idx = -1;
+    best.u = best.v = 0;
+    occluded = false;
+    if (ANYHIT && (cnt & OCC_BIT)) {
+        occluded = true;
+        return true;
+    }
+    cnt &= OCC_BIT - 1;
+    if (cnt > RT_LIST_K) return false;
+    for (int k = 0; k < cnt; ++k) {
+        const int i = list[k];
+        double u, v;
+        const double dist = exact_tri(es, i, S, E, u, v);
+        if ((dist > 0) && (dist < best.t)) {       // :169
+            best.t = dist; best.u = u; best.v = v; best.idx = i;
+            if (ANYHIT) { occluded = true; return true; }
+        }
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(RT_WG)
+k_resolve_primary(ExactScene es, int W, int H, double tan_half, int y0, int y1,
+                  const int32_t* __restrict__ cnt, const int32_t* __restrict__ list,
+                  int32_t* __restrict__ hit, double* __restrict__ tuv,
+                  int32_t* __restrict__ ovf, int* __restrict__ counters)
+{
+    const long npix = (long)W * (y1 - y0);
+    const long p = (long)blockIdx.x * RT_WG + threadIdx.x;
+    if (p >= npix) return;
+    const int py = y0 + (int)(p / W), px = (int)(p % W);
+    double S[3], E[3];
+    primary_ray(W, H, tan_half, px, py, S, E);
+    Best b;
+    bool occ;
+    const int c = cnt[p];
+    if (!confirm_list<false>(es, S, E, c, list + p * RT_LIST_K, b, occ)) {
+        ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
+        return;
+    }
+    atomicAdd(&counters[1], c & (OCC_BIT - 1));
+    hit[p] = b.idx;
+    if (b.idx != -1 && tuv) { tuv[3 * p] = b.t; tuv[3 * p + 1] = b.u; tuv[3 * p + 2] = b.v; }
+}
+
+template <bool ANYHIT>
+__global__ void __launch_bounds__(RT_WG)
+k_resolve_rays(ExactScene es, int n, const double* __restrict__ Sa, const double* __restrict__ Ea,
+               const int32_t* __restrict__ cnt, const int32_t* __restrict__ list,
+               int32_t* __restrict__ hit, double* __restrict__ tuv, double* __restrict__ point,
+               uint8_t* __restrict__ occ_out, int32_t* __restrict__ ovf, int* __restrict__ counters)
+{
+    const long p = (long)blockIdx.x * RT_WG + threadIdx.x;
+    if (p >= n) return;
+    const double S[3] = {Sa[3 * p], Sa[3 * p + 1], Sa[3 * p + 2]};
+    const double E[3] = {Ea[3 * p], Ea[3 * p + 1], Ea[3 * p + 2]};
+    if (!(S[0] == S[0])) {            // unused ray slot
+        if (ANYHIT) occ_out[p] = 0; else hit[p] = -1;
+        return;
+    }
+    Best b;
+    bool occ;
+    const int c = cnt[p];
+    if (!confirm_list<ANYHIT>(es, S, E, c, list + p * RT_LIST_K, b, occ)) {
+        ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
+        return;
+    }
+    atomicAdd(&counters[1], (c & OCC_BIT) ? 0 : (c & (OCC_BIT - 1)));
+    if (ANYHIT) {
+        occ_out[p] = occ ? 1 : 0;
+    } else {
+        hit[p] = b.idx;
+        if (b.idx != -1) {
+            if (tuv) { tuv[3 * p] = b.t; tuv[3 * p + 1] = b.u; tuv[3 * p + 2] = b.v; }
+            if (point) {              // triangle_intersection.cu:185-187
+                point[3 * p] = S[0] + b.t * (E[0] - S[0]);
+                point[3 * p + 1] = S[1] + b.t * (E[1] - S[1]);
+                point[3 * p + 2] = S[2] + b.t * (E[2] - S[2]);
+            }
+        }
+    }
+}
+
+// Full fp64 sweep of one ray by one workgroup.  Thread k visits triangles k, k+256, ... in
+// ascending order with the strict '<' rule, then the 256 partial winners are merged with
+// (smaller t, then smaller index), which is what the sequential host loop would have kept.
+__device__ __forceinline__ Best full_sweep(const ExactScene& es, const double S[3], const double E[3])
+{
+    __shared__ double s_t[RT_WG];
+    __shared__ int s_i[RT_WG];
+    __shared__ double s_u[RT_WG], s_v[RT_WG];
+    Best b;
+    b.t = 1e50; b.idx = -1; b.u = b.v = 0;
+    for (int i = threadIdx.x; i < es.num_tris; i += RT_WG) {
+        double u, v;
+        const double dist = exact_tri(es, i, S, E, u, v);
+        if ((dist > 0) && (dist < b.t)) { b.t = dist; b.u = u; b.v = v; b.idx = i; }
+    }
+    s_t[threadIdx.x] = b.t; s_i[threadIdx.x] = b.idx; s_u[threadIdx.x] = b.u; s_v[threadIdx.x] = b.v;
+    __syncthreads();
+    for (int off = RT_WG / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const int o = threadIdx.x + off;
+            const bool other_hit = s_i[o] != -1, mine_hit = s_i[threadIdx.x] != -1;
+            const bool take = other_hit && (!mine_hit || s_t[o] < s_t[threadIdx.x] ||
+                                            (s_t[o] == s_t[threadIdx.x] && s_i[o] < s_i[threadIdx.x]));
+            if (take) {
+                s_t[threadIdx.x] = s_t[o]; s_i[threadIdx.x] = s_i[o];
+                s_u[threadIdx.x] = s_u[o]; s_v[threadIdx.x] = s_v[o];
+            }
+        }
+        __syncthreads();
+    }
+    b.t = s_t[0]; b.idx = s_i[0]; b.u = s_u[0]; b.v = s_v[0];
+    __syncthreads();
+    return b;
+}
+
+__global__ void __launch_bounds__(RT_WG)
+k_overflow_primary(ExactScene es, int W, int H, double tan_half, int y0,
+                   const int32_t* __restrict__ ovf, const int* __restrict__ counters,
+                   int32_t* __restrict__ hit, double* __restrict__ tuv)
+{
+    const int n = counters[0];
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const long p = ovf[k];
+        const int py = y0 + (int)(p / W), px = (int)(p % W);
+        double S[3], E[3];
+        primary_ray(W, H, tan_half, px, py, S, E);
+        const Best b = full_sweep(es, S, E);
+        if (threadIdx.x == 0) {
+            hit[p] = b.idx;
+            if (b.idx != -1 && tuv) { tuv[3 * p] = b.t; tuv[3 * p + 1] = b.u; tuv[3 * p + 2] = b.v; }
+        }
+    }
+}
+
+template <bool ANYHIT>
+__global__ void __launch_bounds__(RT_WG)
+k_overflow_rays(ExactScene es, const double* __restrict__ Sa, const double* __restrict__ Ea,
+                const int32_t* __restrict__ ovf, const int* __restrict__ counters,
+                int32_t* __restrict__ hit, double* __restrict__ tuv, double* __restrict__ point,
+                uint8_t* __restrict__ occ_out)
+{
+    const int n = counters[0];
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const long p = ovf[k];
+        const double S[3] = {Sa[3 * p], Sa[3 * p + 1], Sa[3 * p + 2]};
+        const double E[3] = {Ea[3 * p], Ea[3 * p + 1], Ea[3 * p + 2]};
+        const Best b = full_sweep(es, S, E);
+        if (threadIdx.x == 0) {
+            if (ANYHIT) {
+                occ_out[p] = b.idx != -1 ? 1 : 0;
+            } else {
+                hit[p] = b.idx;
+                if (b.idx != -1) {
+                    if (tuv) { tuv[3 * p] = b.t; tuv[3 * p + 1] = b.u; tuv[3 * p + 2] = b.v; }
+                    if (point) {
+                        point[3 * p] = S[0] + b.t * (E[0] - S[0]);
+                        point[3 * p + 1] = S[1] + b.t * (E[1] - S[1]);
+                        point[3 * p + 2] = S[2] + b.t * (E[2] - S[2]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// intersect_all_triangles_device: one ray, triangles spread over the whole grid, partial
+// winners merged by a last single-workgroup pass.  SE = S[3],E[3]; out = {idx, t, u, v,
+// point[3]} as 7 doubles (idx stored as a double, exact for any int).
+struct Partial { double t, u, v; int idx; int pad; };
+
+__global__ void __launch_bounds__(RT_WG)
+k_single_ray_partial(ExactScene es, const double* __restrict__ SE, Partial* __restrict__ part)
+{
+    const double S[3] = {SE[0], SE[1], SE[2]};
+    const double E[3] = {SE[3], SE[4], SE[5]};
+    __shared__ double s_t[RT_WG];
+    __shared__ int s_i[RT_WG];
+    __shared__ double s_u[RT_WG], s_v[RT_WG];
+    Best b;
+    b.t = 1e50; b.idx = -1; b.u = b.v = 0;
+    for (long i = (long)blockIdx.x * RT_WG + threadIdx.x; i < es.num_tris; i += (long)gridDim.x * RT_WG) {
+        double u, v;
+        const double dist = exact_tri(es, (int)i, S, E, u, v);
+        if ((dist > 0) && (dist < b.t)) { b.t = dist; b.u = u; b.v = v; b.idx = (int)i; }
+    }
+    s_t[threadIdx.x] = b.t; s_i[threadIdx.x] = b.idx; s_u[threadIdx.x] = b.u; s_v[threadIdx.x] = b.v;
+    __syncthreads();
+    for (int off = RT_WG / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const int o = threadIdx.x + off;
+            const bool other_hit = s_i[o] != -1, mine_hit = s_i[threadIdx.x] != -1;
+            const bool take = other_hit && (!mine_hit || s_t[o] < s_t[threadIdx.x] ||
+                                            (s_t[o] == s_t[threadIdx.x] && s_i[o] < s_i[threadIdx.x]));
+            if (take) {
+                s_t[threadIdx.x] = s_t[o]; s_i[threadIdx.x] = s_i[o];
+                s_u[threadIdx.x] = s_u[o]; s_v[threadIdx.x] = s_v[o];
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[blockIdx.x].t = s_t[0]; part[blockIdx.x].idx = s_i[0];
+        part[blockIdx.x].u = s_u[0]; part[blockIdx.x].v = s_v[0];
+    }
+}
+
+__global__ void k_single_ray_final(const Partial* __restrict__ part, int nparts,
+                                   const double* __restrict__ SE, double* __restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Best b;
+    b.t = 1e50; b.idx = -1; b.u = b.v = 0;
+    for (int k = 0; k < nparts; ++k) {
+        if (part[k].idx == -1) continue;
+        if (b.idx == -1 || part[k].t < b.t || (part[k].t == b.t && part[k].idx < b.idx)) {
+            b.t = part[k].t; b.idx = part[k].idx; b.u = part[k].u; b.v = part[k].v;
+        }
+    }
+    out[0] = (double)b.idx;
+    out[1] = b.t; out[2] = b.u; out[3] = b.v;
+    if (b.idx != -1) {
+        out[4] = SE[0] + b.t * (SE[3] - SE[0]);
+        out[5] = SE[1] + b.t * (SE[4] - SE[1]);
+        out[6] = SE[2] + b.t * (SE[5] - SE[2]);
+    }
+}
+
+int launched(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        rt_set_error("%s launch failed: %s", what, hipGetErrorString(e));
+        return RT_E_HIP;
+    }
+    return RT_OK;
+}
+
+constexpr int OVERFLOW_GRID = 2048;
+constexpr int SINGLE_RAY_GRID = 256;
+
+}  // namespace
+
+int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_half, int y0, int y1,
+                              const int32_t* cnt, const int32_t* list, int32_t* hit, double* tuv,
+                              int32_t* ovf, int* counters, hipStream_t st)
+{
+    const long npix = (long)W * (y1 - y0);
+    if (npix <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_resolve_primary, dim3((unsigned)((npix + RT_WG - 1) / RT_WG)), dim3(RT_WG),
+                       0, st, es, W, H, tan_half, y0, y1, cnt, list, hit, tuv, ovf, counters);
+    return launched("resolve_primary");
+}
+
+int rt_launch_resolve_rays(const ExactScene& es, int n, const double* S, const double* E,
+                           const int32_t* cnt, const int32_t* list, bool anyhit, int32_t* hit,
+                           double* tuv, double* point, uint8_t* occ, int32_t* ovf, int* counters,
+                           hipStream_t st)
+{
+    if (n <= 0) return RT_OK;
+    dim3 grid((n + RT_WG - 1) / RT_WG);
+    if (anyhit)
+        hipLaunchKernelGGL(k_resolve_rays<true>, grid, dim3(RT_WG), 0, st, es, n, S, E, cnt, list,
+                           hit, tuv, point, occ, ovf, counters);
+    else
+        hipLaunchKernelGGL(k_resolve_rays<false>, grid, dim3(RT_WG), 0, st, es, n, S, E, cnt, list,
+                           hit, tuv, point, occ, ovf, counters);
+    return launched("resolve_rays");
+}
+
+int rt_launch_overflow_primary(const ExactScene& es, int W, int H, double tan_half, int y0,
+                               const int32_t* ovf, const int* counters, int32_t* hit, double* tuv,
+                               hipStream_t st)
+{
+    hipLaunchKernelGGL(k_overflow_primary, dim3(OVERFLOW_GRID), dim3(RT_WG), 0, st, es, W, H,
+                       tan_half, y0, ovf, counters, hit, tuv);
+    return launched("overflow_primary");
+}
+
+int rt_launch_overflow_rays(const ExactScene& es, const double* S, const double* E,
+                            const int32_t* ovf, const int* counters, bool anyhit, int32_t* hit,
+                            double* tuv, double* point, uint8_t* occ, hipStream_t st)
+{
+    if (anyhit)
+        hipLaunchKernelGGL(k_overflow_rays<true>, dim3(OVERFLOW_GRID), dim3(RT_WG), 0, st, es, S, E,
+                           ovf, counters, hit, tuv, point, occ);
+    else
+        hipLaunchKernelGGL(k_overflow_rays<false>, dim3(OVERFLOW_GRID), dim3(RT_WG), 0, st, es, S, E,
+                           ovf, counters, hit, tuv, point, occ);
+    return launched("overflow_rays");
+}
+
+// out_dev: 7 doubles followed by SINGLE_RAY_GRID Partial records of workspace.
+int rt_launch_single_ray(const ExactScene& es, const double* SE_dev, double* out_dev, hipStream_t st)
+{
+    Partial* part = reinterpret_cast<Partial*>(out_dev + 8);
+    int grid = (es.num_tris + RT_WG - 1) / RT_WG;
+    if (grid > SINGLE_RAY_GRID) grid = SINGLE_RAY_GRID;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_single_ray_partial, dim3(grid), dim3(RT_WG), 0, st, es, SE_dev, part);
+    int rc = launched("single_ray_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_single_ray_final, dim3(1), dim3(64), 0, st, part, grid, SE_dev, out_dev);
+    return launched("single_ray_final");
+}

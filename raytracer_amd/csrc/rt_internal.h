@@ -1,0 +1,182 @@
+// rt_internal.h -- shared declarations of the library's translation units (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+
+// ---------------------------------------------------------------- error plumbing
+void rt_set_error(const char* fmt, ...);
+
+#define RT_HIP(call)                                                                    \
+    do {                                                                                \
+        hipError_t rt_e_ = (call);                                                      \
+        if (rt_e_ != hipSuccess) {                                                      \
+            rt_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call,             \
+                         hipGetErrorString(rt_e_));                                     \
+            return RT_E_HIP;                                                            \
+        }                                                                               \
+    } while (0)
+
+#define RT_ARG(cond, msg)                                                               \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            rt_set_error("%s: %s", __func__, msg);                                      \
+            return RT_E_ARG;                                                            \
+        }                                                                               \
+    } while (0)
+
+// ---------------------------------------------------------------- tunables
+constexpr int RT_WG = 256;          // threads per workgroup of every kernel here (4 waves)
+constexpr int RT_TILE = 256;        // triangles per LDS tile of the sweep
+constexpr int RT_RPL = 2;           // rays per lane in the sweep
+constexpr int RT_LIST_K = 16;       // candidate slots per ray handed to the fp64 confirmation
+constexpr int RT_TILE_W = 16 * RT_RPL;   // pixel tile of one workgroup: 2x2 waves of (8*RPL)x8
+constexpr int RT_TILE_H = 16;
+constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
+
+// ---------------------------------------------------------------- device buffer helper
+// Grow-only device allocation; keeps steady-state frames free of hipMalloc/hipFree.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);   // returns RT_OK / RT_E_HIP
+    void release();
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// ---------------------------------------------------------------- scene
+struct rt_scene {
+    int num_v = 0, num_vn = 0, num_vt = 0, num_tris = 0, num_mats = 0, num_tex = 0;
+    int num_tris_padded = 0;
+    bool transformed = false;
+
+    // object-space master + eye-space working copy, fp64 SoA, 1-indexed (slot 0 carried along)
+    DevBuf ox, oy, oz, ex, ey, ez;
+    DevBuf nx, ny, nz;          // normals, object space, fp64
+    DevBuf tu, tv;              // texture coordinates
+    DevBuf iA, iB, iC, iAn, iBn, iCn, iAt, iBt, iCt, imtl;   // int32 per triangle
+    DevBuf mats;                // DevMaterial[num_mats]
+    DevBuf tex_desc;            // DevTexture[num_tex]
+    std::vector<DevBuf> tex_data;
+    bool has_tex_idx = false;
+
+    // fp32 sweep buffer: three float4 planes of num_tris_padded entries
+    //   v0 = (A.x, A.y, A.z, eu)   e1 = (B-A, et)   e2 = (C-A, 0)
+    DevBuf pv0, pe1, pe2;
+    DevBuf scratch_max;         // 1 float: max |coordinate| of the eye-space vertices
+
+    // per-call workspaces (grow-only)
+    DevBuf ws_cnt, ws_list, ws_ovf, ws_counters;
+    DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_shcnt, ws_shlist;
+};
+
+struct DevMaterial {
+    double Ka[3], Kd[3], Ks[3];
+    int map_Ka, map_Kd, map_Ks, pad;
+};
+struct DevTexture {
+    const uint8_t* rgb;
+    int w, h;
+};
+
+struct DevFrame {           // what the shading kernels read
+    int num_lights;
+    int pad;
+    double obinv[4][4];
+    double light_pos[RT_MAX_LIGHTS][3];
+    double light_rgb[RT_MAX_LIGHTS][3];
+    double light_att[RT_MAX_LIGHTS][2];
+    double light_max[RT_MAX_LIGHTS];
+};
+
+// ---------------------------------------------------------------- global state (rt_api.hip)
+struct RtGlobal {
+    bool inited = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool profiling = false;
+    rt_profile prof{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+RtGlobal& rt_g();
+int rt_ensure_init();
+
+// ---------------------------------------------------------------- launchers (defined per .hip file)
+// rt_transform.hip
+int rt_launch_transform(const double* m16, const double* x, const double* y, const double* z,
+                        double* X, double* Y, double* Z, int n, unsigned* max_bits, hipStream_t st);
+int rt_launch_pack(rt_scene* sc, hipStream_t st);
+
+// rt_sweep.hip
+struct SweepArgs {
+    const float4 *v0, *e1, *e2;
+    int num_tris, num_tris_padded;
+    // primary mode
+    int W, H, y0, y1;
+    double ez;              // (W/2)/tan_half, integer W/2 (driver.c:133)
+    // generic mode
+    int n_rays;
+    const double *S, *E;    // 3 doubles per ray
+    // outputs
+    int32_t* cnt;           // per ray slot: number of candidates pushed (bit 31: certainly occluded)
+    int32_t* list;          // RT_LIST_K candidate triangle indices per ray slot
+    unsigned long long* tests;   // any-hit: pairs evaluated, accumulated per workgroup
+};
+int rt_launch_sweep_primary(const SweepArgs& a, hipStream_t st);
+int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st);
+int rt_primary_slots(int W, int y0, int y1);      // ray slots (tile-padded) of a band
+
+// rt_exact.hip
+struct ExactScene {
+    const double *x, *y, *z;
+    const int *A, *B, *C;
+    int num_tris;
+};
+int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_half, int y0, int y1,
+                              const int32_t* cnt, const int32_t* list,
+                              int32_t* hit, double* tuv, int32_t* ovf, int* counters,
+                              hipStream_t st);
+int rt_launch_resolve_rays(const ExactScene& es, int n, const double* S, const double* E,
+                           const int32_t* cnt, const int32_t* list, bool anyhit,
+                           int32_t* hit, double* tuv, double* point, uint8_t* occ,
+                           int32_t* ovf, int* counters, hipStream_t st);
+int rt_launch_overflow_primary(const ExactScene& es, int W, int H, double tan_half, int y0,
+                               const int32_t* ovf, const int* counters,
+                               int32_t* hit, double* tuv, hipStream_t st);
+int rt_launch_overflow_rays(const ExactScene& es, const double* S, const double* E,
+                            const int32_t* ovf, const int* counters, bool anyhit,
+                            int32_t* hit, double* tuv, double* point, uint8_t* occ,
+                            hipStream_t st);
+int rt_launch_single_ray(const ExactScene& es, const double* S_E_dev, double* out_dev,
+                         hipStream_t st);
+
+// rt_shade.hip
+struct ShadeArgs {
+    ExactScene es;
+    const int *An, *Bn, *Cn, *At, *Bt, *Ct, *mtl;
+    const double *nx, *ny, *nz, *tu, *tv;
+    const DevMaterial* mats;
+    const DevTexture* tex;
+    int num_mats;
+    const DevFrame* frame;
+    int num_lights;
+    int W, H, y0, y1;
+    double tan_half;
+    const int32_t* hit;       // per pixel (band-local)
+    const double* tuv;
+    double *shS, *shE;        // shadow rays: [light][pixel] 3 doubles each
+    const uint8_t* occ;       // [light][pixel]
+    double* argb;
+    uint8_t* rgb8;
+};
+int rt_launch_shadow_setup(const ShadeArgs& a, hipStream_t st);
+int rt_launch_shade_final(const ShadeArgs& a, hipStream_t st);
+int rt_launch_place_rows(const uint8_t* rgb8, int W, int H, int y0, int y1, uint8_t* screen,
+                         hipStream_t st);

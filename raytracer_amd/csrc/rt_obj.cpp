@@ -1,0 +1,539 @@
+// rt_obj.cpp -- Wavefront .obj / .mtl loader with the reference's semantics, emitting
+// structure-of-arrays buffers (page-locked when a GPU is present) instead of the reference's
+// 488-byte array-of-structures with a Material copy per triangle.
+//
+// Behaviour follows obj_reader.c:
+//   * tokens are whitespace-delimited and read like fscanf("%s") does, across line ends (:664);
+//   * v / vt / vn append to 1-indexed arrays (:666-680; slot 0 exists and is zero here,
+//     uninitialised in the reference);
+//   * the face format is sniffed from the first vertex (:27-48): 1 = v, 2 = v/vt,
+//     3 = v/vt/vn, 4 = v//vn;
+//   * a fourth vertex makes a quad, split (a,b,c) + (a,c,d) (:167-231); a fifth is an error
+//     (:500-505; the reference exits the process, this loader returns RT_E_IO);
+//   * formats without vn get ONE un-normalised face normal AB x AC, computed from the
+//     coordinates as read (before centring/scaling) and shared by both halves of a quad
+//     (:51-82,180,196);
+//   * `usemtl` selects the material copied into following triangles (:84-90,708-716), here an
+//     index into the material table; -1 until the first successful usemtl (:18);
+//   * after parsing, vertices are centred on their mean and scaled so the largest bounding
+//     box extent is 15 (:239-289), slot 0 included (:288).
+// One evident defect is not reproduced: for format 1 the reference stores the ADDRESS of its
+// scratch array as the vertex index of the first triangle of each face (:98-100); the
+// index itself is stored here.
+//
+// Image maps: the reference decodes them with SDL_image (:352-381) and keeps a NULL map when
+// decoding fails.  This loader decodes binary PPM (P6) and uncompressed 24/32-bit BMP; any
+// other format is treated like a failed IMG_Load (the material keeps its constant colour).
+#include <hip/hip_runtime_api.h>
+
+#include <cctype>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+
+void rt_set_error(const char* fmt, ...);
+
+namespace {
+
+// ---------------------------------------------------------------- fscanf-like cursor
+struct Cursor {
+    const char* p;
+    const char* end;
+    bool eof() const { return p >= end; }
+    void skip_ws() { while (p < end && isspace((unsigned char)*p)) ++p; }
+    bool token(std::string& out)                     // "%s"
+    {
+        skip_ws();
+        if (eof()) return false;
+        const char* s = p;
+        while (p < end && !isspace((unsigned char)*p)) ++p;
+        out.assign(s, p);
+        return true;
+    }
+    bool integer(int& v)                             // "%d": on failure nothing past the
+    {                                                // leading white space is consumed
+        skip_ws();
+        const char* s = p;
+        if (s < end && (*s == '+' || *s == '-')) ++s;
+        if (s >= end || !isdigit((unsigned char)*s)) return false;
+        char* e = nullptr;
+        const long val = strtol(p, &e, 10);
+        if (e == p) return false;
+        v = (int)val;
+        p = e;
+        return true;
+    }
+    bool real(double& v)                             // "%lf"
+    {
+        skip_ws();
+        if (eof()) return false;
+        const char c = *p;
+        if (!(isdigit((unsigned char)c) || c == '+' || c == '-' || c == '.')) return false;
+        char* e = nullptr;
+        const double val = strtod(p, &e);
+        if (e == p) return false;
+        v = val;
+        p = e;
+        return true;
+    }
+    bool literal(char c)                             // a literal in a scanf format: no skipping
+    {
+        if (p < end && *p == c) { ++p; return true; }
+        return false;
+    }
+    void skip_line()                                 // fgets to the end of the line
+    {
+        while (p < end && *p != '\n') ++p;
+        if (p < end) ++p;
+    }
+};
+
+bool read_file(const std::string& path, std::string& out)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[1 << 16];
+    size_t n;
+    out.clear();
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    fclose(f);
+    return true;
+}
+
+// ---------------------------------------------------------------- images
+struct Image {
+    int w = 0, h = 0;
+    std::vector<uint8_t> rgb;
+};
+
+bool load_ppm(const std::string& data, Image& im)
+{
+    Cursor c{data.data(), data.data() + data.size()};
+    std::string tok;
+    if (!c.token(tok) || tok != "P6") return false;
+    int vals[3], got = 0;
+    while (got < 3) {
+        c.skip_ws();
+        if (!c.eof() && *c.p == '#') { c.skip_line(); continue; }
+        if (!c.integer(vals[got])) return false;
+        ++got;
+    }
+    if (vals[0] <= 0 || vals[1] <= 0 || vals[2] != 255) return false;
+    ++c.p;      // the single white-space byte after maxval
+    const size_t need = (size_t)vals[0] * vals[1] * 3;
+    if ((size_t)(c.end - c.p) < need) return false;
+    im.w = vals[0]; im.h = vals[1];
+    im.rgb.assign((const uint8_t*)c.p, (const uint8_t*)c.p + need);
+    return true;
+}
+
+bool load_bmp(const std::string& d, Image& im)
+{
+    if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') return false;
+    auto u32 = [&](size_t o) {
+        return (uint32_t)(uint8_t)d[o] | (uint32_t)(uint8_t)d[o + 1] << 8 |
+               (uint32_t)(uint8_t)d[o + 2] << 16 | (uint32_t)(uint8_t)d[o + 3] << 24;
+    };
+    const uint32_t off = u32(10);
+    const int32_t w = (int32_t)u32(18), hs = (int32_t)u32(22);
+    const int bpp = (uint8_t)d[28] | (uint8_t)d[29] << 8;
+    const uint32_t comp = u32(30);
+    if (w <= 0 || hs == 0 || (bpp != 24 && bpp != 32) || (comp != 0 && comp != 3)) return false;
+    const int h = hs < 0 ? -hs : hs;
+    const size_t stride = ((size_t)w * (bpp / 8) + 3) & ~(size_t)3;
+    if (d.size() < off + stride * (size_t)h) return false;
+    im.w = w; im.h = h;
+    im.rgb.resize((size_t)w * h * 3);
+    for (int y = 0; y < h; ++y) {
+        const int src_row = hs < 0 ? y : h - 1 - y;          // top row first in `im`
+        const uint8_t* s = (const uint8_t*)d.data() + off + stride * (size_t)src_row;
+        for (int x = 0; x < w; ++x) {
+            const uint8_t* px = s + (size_t)x * (bpp / 8);
+            uint8_t* o = &im.rgb[((size_t)y * w + x) * 3];
+            o[0] = px[2]; o[1] = px[1]; o[2] = px[0];
+        }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- parsed object
+struct MaterialRec {
+    std::string name;
+    double Ka[3] = {1.0, 1.0, 1.0}, Kd[3] = {1.0, 1.0, 1.0}, Ks[3] = {1.0, 1.0, 1.0};   // :296-298
+    int map_Ka = -1, map_Kd = -1, map_Ks = -1;
+};
+
+}  // namespace
+
+struct rt_obj {
+    int num_v = 0, num_vn = 0, num_vt = 0, num_tris = 0, num_mats = 0;
+    bool pinned = false;
+    // single allocation carved into the arrays of rt_obj_view
+    void* block = nullptr;
+    rt_obj_view view{};
+    std::vector<Image> textures;
+    std::vector<std::string> texture_names;
+};
+
+namespace {
+
+struct Builder {
+    std::vector<double> x{0.0}, y{0.0}, z{0.0}, xn{0.0}, yn{0.0}, zn{0.0}, u{0.0}, v{0.0};
+    std::vector<int> idx[9];    // A B C  An Bn Cn  At Bt Ct
+    std::vector<int> mtl;
+    std::vector<MaterialRec> mats;
+    std::vector<Image> textures;
+    std::vector<std::string> texture_names;
+    int current_mat = -1;
+    std::string dir;
+    std::string err;
+
+    int num_v() const { return (int)x.size() - 1; }
+    int num_vn() const { return (int)xn.size() - 1; }
+    int num_vt() const { return (int)u.size() - 1; }
+
+    void push_tri(const int v[3], const int vt[3], const int vn[3])
+    {
+        for (int k = 0; k < 3; ++k) {
+            idx[0 + k].push_back(v[k]);
+            idx[3 + k].push_back(vn[k]);
+            idx[6 + k].push_back(vt[k]);
+        }
+        mtl.push_back(current_mat);                          // set_mtl, :84-90
+    }
+
+    // find_and_add_normal, :51-82 with M3d_x_product (M3d_matrix_tools.c:220-222)
+    int add_face_normal(int A, int B, int C)
+    {
+        const double AB[3] = {x[B] - x[A], y[B] - y[A], z[B] - z[A]};
+        const double AC[3] = {x[C] - x[A], y[C] - y[A], z[C] - z[A]};
+        xn.push_back(AB[1] * AC[2] - AC[1] * AB[2]);
+        yn.push_back(AC[0] * AB[2] - AB[0] * AC[2]);
+        zn.push_back(AB[0] * AC[1] - AC[0] * AB[1]);
+        return num_vn();
+    }
+
+    // get_face_format, :27-48
+    static int face_format(Cursor c)
+    {
+        int a, n = 0;
+        if (!c.integer(a)) return 0;
+        n = 1;
+        if (c.literal('/')) {
+            if (c.integer(a)) {
+                n = 2;
+                if (c.literal('/') && c.integer(a)) n = 3;
+            }
+        }
+        if (n == 1) return c.literal('/') ? 4 : 1;
+        return n;
+    }
+
+    // one vertex reference in the given format; false = not there (cursor untouched)
+    static bool face_vertex(Cursor& c, int format, int& v, int& vt, int& vn)
+    {
+        Cursor save = c;
+        vt = vn = 0;
+        bool ok = c.integer(v);
+        if (ok && format == 2) ok = c.literal('/') && c.integer(vt);
+        if (ok && format == 3) ok = c.literal('/') && c.integer(vt) && c.literal('/') && c.integer(vn);
+        if (ok && format == 4) ok = c.literal('/') && c.literal('/') && c.integer(vn);
+        if (!ok) c = save;
+        return ok;
+    }
+
+    bool check_index(int i, int n, const char* what)
+    {
+        if (i >= 1 && i <= n) return true;
+        char buf[160];
+        snprintf(buf, sizeof buf, "%s index %d outside [1,%d] (relative indices are not supported)",
+                 what, i, n);
+        err = buf;
+        return false;
+    }
+
+    // scan_face, :233-237
+    bool face(Cursor& c)
+    {
+        const int format = face_format(c);
+        if (format == 0) { err = "face without vertices"; return false; }
+        int v[5], vt[5], vn[5], n = 0;
+        while (n < 5 && face_vertex(c, format, v[n], vt[n], vn[n])) ++n;
+        if (n < 3) { err = "face with fewer than 3 vertices"; return false; }
+        if (n > 4) { err = "The object contains a face with more than 4 vertices"; return false; }
+        for (int k = 0; k < n; ++k) {
+            if (!check_index(v[k], num_v(), "vertex")) return false;
+            if ((format == 2 || format == 3) && !check_index(vt[k], num_vt(), "texture")) return false;
+            if ((format == 3 || format == 4) && !check_index(vn[k], num_vn(), "normal")) return false;
+        }
+        if (format == 1 || format == 2) {
+            const int fn = add_face_normal(v[0], v[1], v[2]);
+            for (int k = 0; k < n; ++k) vn[k] = fn;
+        }
+        const int t0v[3] = {v[0], v[1], v[2]}, t0t[3] = {vt[0], vt[1], vt[2]}, t0n[3] = {vn[0], vn[1], vn[2]};
+        push_tri(t0v, t0t, t0n);
+        if (n == 4) {                                        // :167-231: (a, c, d)
+            const int t1v[3] = {v[0], v[2], v[3]}, t1t[3] = {vt[0], vt[2], vt[3]}, t1n[3] = {vn[0], vn[2], vn[3]};
+            push_tri(t1v, t1t, t1n);
+        }
+        return true;
+    }
+
+    int load_texture(const std::string& name)
+    {
+        std::string data;
+        Image im;
+        if (!read_file(dir + name, data) || !(load_ppm(data, im) || load_bmp(data, im))) {
+            fprintf(stderr, "rt_obj: cannot decode image map %s%s (kept as a constant colour)\n",
+                    dir.c_str(), name.c_str());
+            return -1;                                       // IMG_Load failed, :360-363
+        }
+        textures.push_back(std::move(im));
+        texture_names.push_back(name);
+        return (int)textures.size() - 1;
+    }
+
+    // read_mtl_file, :383-453
+    bool read_mtl(const std::string& path)
+    {
+        std::string data;
+        if (!read_file(path, data)) { err = "can't open file, " + path; return false; }
+        Cursor c{data.data(), data.data() + data.size()};
+        std::string key, name;
+        auto three = [&](double d[3]) { c.real(d[0]) && c.real(d[1]) && c.real(d[2]); };
+        double dump[3];
+        while (c.token(key)) {
+            MaterialRec* cur = mats.empty() ? nullptr : &mats.back();
+            if (key == "newmtl") {
+                MaterialRec m;
+                c.token(m.name);
+                mats.push_back(m);
+            } else if (key == "Ka" && cur) three(cur->Ka);
+            else if (key == "Kd" && cur) three(cur->Kd);
+            else if (key == "Ks" && cur) three(cur->Ks);
+            else if (key == "Ke" || key == "Tf") three(dump);
+            else if (key == "map_Ka" && cur) { c.token(name); cur->map_Ka = load_texture(name); }
+            else if (key == "map_Kd" && cur) { c.token(name); cur->map_Kd = load_texture(name); }
+            else if (key == "map_Ks" && cur) { c.token(name); cur->map_Ks = load_texture(name); }
+            else if (key == "Tr" || key == "Ns" || key == "Ni" || key == "d") c.real(dump[0]);
+            else if (key == "illum") { int i; c.integer(i); }
+            else c.skip_line();                              // map_bump, '#', anything else
+        }
+        return true;
+    }
+
+    bool parse(const std::string& path)
+    {
+        std::string data;
+        if (!read_file(path, data)) { err = "can't open file, " + path; return false; }
+        const size_t slash = path.find_last_of("/\\");
+        dir = slash == std::string::npos ? "" : path.substr(0, slash + 1);
+        Cursor c{data.data(), data.data() + data.size()};
+        std::string key, name;
+        while (c.token(key)) {
+            if (key == "v") {                                // :666-670 (optional w is swallowed)
+                double p[4] = {0, 0, 0, 0};
+                c.real(p[0]) && c.real(p[1]) && c.real(p[2]) && c.real(p[3]);
+                x.push_back(p[0]); y.push_back(p[1]); z.push_back(p[2]);
+            } else if (key == "vt") {                        // :671-675
+                double p[2] = {0, 0};
+                c.real(p[0]) && c.real(p[1]);
+                u.push_back(p[0]); v.push_back(p[1]);
+            } else if (key == "vn") {                        // :676-680
+                double p[3] = {0, 0, 0};
+                c.real(p[0]) && c.real(p[1]) && c.real(p[2]);
+                xn.push_back(p[0]); yn.push_back(p[1]); zn.push_back(p[2]);
+            } else if (key == "g" || key == "s") {           // :684-691
+                c.token(name);
+            } else if (key == "f") {                         // :692-697
+                if (!face(c)) return false;
+            } else if (key == "mtllib") {                    // :698-707
+                c.token(name);
+                if (!read_mtl(dir + name)) return false;
+            } else if (key == "usemtl") {                    // :708-716
+                c.token(name);
+                for (size_t i = 0; i < mats.size(); ++i)
+                    if (mats[i].name == name) { current_mat = (int)i; break; }
+            } else if (key[0] == '#') {                      // :717-719
+                c.skip_line();
+            }
+            // any other keyword ("vp", "o", ...): ignored, its arguments are read as further
+            // unknown keywords, as in the reference's second pass
+        }
+        if (num_v() < 1) { err = "object has no vertices"; return false; }
+        return true;
+    }
+
+    // center_and_scale_object, :239-289; m = S*T applied like mat_mult.cu:20-22
+    void center_and_scale()
+    {
+        const int n = num_v();
+        double xc = 0, yc = 0, zc = 0;
+        double lo[3] = {x[1], y[1], z[1]}, hi[3] = {x[1], y[1], z[1]};
+        for (int i = 1; i <= n; ++i) {
+            xc += x[i]; yc += y[i]; zc += z[i];
+            if (x[i] < lo[0]) lo[0] = x[i];
+            if (y[i] < lo[1]) lo[1] = y[i];
+            if (z[i] < lo[2]) lo[2] = z[i];
+            if (x[i] > hi[0]) hi[0] = x[i];
+            if (y[i] > hi[1]) hi[1] = y[i];
+            if (z[i] > hi[2]) hi[2] = z[i];
+        }
+        xc /= n; yc /= n; zc /= n;
+        const double xd = hi[0] - lo[0], yd = hi[1] - lo[1], zd = hi[2] - lo[2];
+        double delta;
+        if ((xd > yd) && (xd > zd)) delta = xd;
+        else if (yd > zd) delta = yd;
+        else delta = zd;
+        const double sf = 15 / delta;
+        const double t[4][4] = {{1, 0, 0, -xc}, {0, 1, 0, -yc}, {0, 0, 1, -zc}, {0, 0, 0, 1}};
+        const double s[4][4] = {{sf, 0, 0, 0}, {0, sf, 0, 0}, {0, 0, sf, 0}, {0, 0, 0, 1}};
+        double m[4][4];
+        rt_mat_mult(m, s, t);                                // M3d_mat_mult(m, s, t), :286
+        for (int i = 0; i <= n; ++i) {
+            const double px = x[i], py = y[i], pz = z[i];
+            x[i] = m[0][0] * px + m[0][1] * py + m[0][2] * pz + m[0][3];
+            y[i] = m[1][0] * px + m[1][1] * py + m[1][2] * pz + m[1][3];
+            z[i] = m[2][0] * px + m[2][1] * py + m[2][2] * pz + m[2][3];
+        }
+    }
+};
+
+template <class T>
+T* carve(char*& cur, size_t count)
+{
+    T* p = reinterpret_cast<T*>(cur);
+    cur += ((count * sizeof(T) + 63) / 64) * 64;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int rt_obj_load(const char* path, rt_obj** out)
+{
+    if (!path || !out) {
+        rt_set_error("rt_obj_load: null pointer");
+        return RT_E_ARG;
+    }
+    Builder b;
+    if (!b.parse(path)) {
+        rt_set_error("rt_obj_load: %s", b.err.c_str());
+        return RT_E_IO;
+    }
+    b.center_and_scale();
+
+    rt_obj* o = new rt_obj();
+    o->num_v = b.num_v(); o->num_vn = b.num_vn(); o->num_vt = b.num_vt();
+    o->num_tris = (int)b.mtl.size(); o->num_mats = (int)b.mats.size();
+    const size_t nv = o->num_v + 1, nn = o->num_vn + 1, nt = o->num_vt + 1, ntri = o->num_tris,
+                 nm = o->num_mats;
+    const size_t bytes = 64 * 32 + sizeof(double) * (3 * nv + 3 * nn + 2 * nt + 9 * nm) +
+                         sizeof(int) * (10 * ntri + 3 * nm);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 &&
+        hipHostMalloc(&o->block, bytes, hipHostMallocDefault) == hipSuccess) {
+        o->pinned = true;
+    } else {
+        (void)hipGetLastError();
+        o->block = aligned_alloc(64, (bytes + 63) / 64 * 64);
+        o->pinned = false;
+    }
+    if (!o->block) {
+        delete o;
+        rt_set_error("rt_obj_load: out of memory");
+        return RT_E_IO;
+    }
+    char* cur = static_cast<char*>(o->block);
+    rt_obj_view& v = o->view;
+    auto put_d = [&](const std::vector<double>& src) {
+        double* p = carve<double>(cur, src.size());
+        memcpy(p, src.data(), src.size() * sizeof(double));
+        return p;
+    };
+    auto put_i = [&](const std::vector<int>& src) {
+        int* p = carve<int>(cur, src.size());
+        if (!src.empty()) memcpy(p, src.data(), src.size() * sizeof(int));
+        return p;
+    };
+    v.num_v = o->num_v; v.num_vn = o->num_vn; v.num_vt = o->num_vt;
+    v.num_tris = o->num_tris; v.num_mats = o->num_mats;
+    v.x = put_d(b.x); v.y = put_d(b.y); v.z = put_d(b.z);
+    v.xn = put_d(b.xn); v.yn = put_d(b.yn); v.zn = put_d(b.zn);
+    v.u = put_d(b.u); v.v = put_d(b.v);
+    v.A = put_i(b.idx[0]); v.B = put_i(b.idx[1]); v.C = put_i(b.idx[2]);
+    v.An = put_i(b.idx[3]); v.Bn = put_i(b.idx[4]); v.Cn = put_i(b.idx[5]);
+    v.At = put_i(b.idx[6]); v.Bt = put_i(b.idx[7]); v.Ct = put_i(b.idx[8]);
+    v.mtl = put_i(b.mtl);
+    std::vector<double> Ka(3 * nm), Kd(3 * nm), Ks(3 * nm);
+    std::vector<int> mKa(nm), mKd(nm), mKs(nm);
+    for (size_t i = 0; i < nm; ++i) {
+        for (int k = 0; k < 3; ++k) {
+            Ka[3 * i + k] = b.mats[i].Ka[k]; Kd[3 * i + k] = b.mats[i].Kd[k]; Ks[3 * i + k] = b.mats[i].Ks[k];
+        }
+        mKa[i] = b.mats[i].map_Ka; mKd[i] = b.mats[i].map_Kd; mKs[i] = b.mats[i].map_Ks;
+    }
+    v.Ka = put_d(Ka); v.Kd = put_d(Kd); v.Ks = put_d(Ks);
+    v.map_Ka = put_i(mKa); v.map_Kd = put_i(mKd); v.map_Ks = put_i(mKs);
+    v.pinned = o->pinned ? 1 : 0;
+    o->textures = std::move(b.textures);
+    o->texture_names = std::move(b.texture_names);
+    *out = o;
+    return RT_OK;
+}
+
+extern "C" int rt_obj_free(rt_obj* o)
+{
+    if (!o) return RT_OK;
+    if (o->block) {
+        if (o->pinned) (void)hipHostFree(o->block);
+        else free(o->block);
+    }
+    delete o;
+    return RT_OK;
+}
+
+extern "C" int rt_obj_get(const rt_obj* o, rt_obj_view* out)
+{
+    if (!o || !out) {
+        rt_set_error("rt_obj_get: null pointer");
+        return RT_E_ARG;
+    }
+    *out = o->view;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_obj(rt_scene* sc, const rt_obj* o)
+{
+    if (!sc || !o) {
+        rt_set_error("rt_scene_set_obj: null pointer");
+        return RT_E_ARG;
+    }
+    const rt_obj_view& v = o->view;
+    int rc = rt_scene_set_vertices(sc, v.num_v, v.x, v.y, v.z);
+    if (rc) return rc;
+    rc = rt_scene_set_normals(sc, v.num_vn, v.xn, v.yn, v.zn);
+    if (rc) return rc;
+    rc = rt_scene_set_texcoords(sc, v.num_vt, v.u, v.v);
+    if (rc) return rc;
+    if (!o->textures.empty()) {
+        std::vector<int> w, h;
+        std::vector<const uint8_t*> px;
+        for (const Image& im : o->textures) { w.push_back(im.w); h.push_back(im.h); px.push_back(im.rgb.data()); }
+        rc = rt_scene_set_textures(sc, (int)w.size(), w.data(), h.data(), px.data());
+        if (rc) return rc;
+    }
+    rc = rt_scene_set_materials(sc, v.num_mats, v.Ka, v.Kd, v.Ks, v.map_Ka, v.map_Kd, v.map_Ks);
+    if (rc) return rc;
+    const bool tex = v.num_vt > 0;
+    bool tex_ok = tex;
+    for (int i = 0; tex_ok && i < v.num_tris; ++i)
+        tex_ok = v.At[i] >= 1 && v.Bt[i] >= 1 && v.Ct[i] >= 1;
+    return rt_scene_set_triangles(sc, v.num_tris, v.A, v.B, v.C, v.An, v.Bn, v.Cn,
+                                  tex_ok ? v.At : nullptr, tex_ok ? v.Bt : nullptr,
+                                  tex_ok ? v.Ct : nullptr, v.mtl);
+}

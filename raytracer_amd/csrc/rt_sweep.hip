@@ -1,0 +1,303 @@
+// rt_sweep.hip -- the hot kernel: brute-force ray-triangle sweep for gfx950.
+//
+// Replaces the per-ray launch of intersect_single_triangle_device
+// (triangle_intersection.cu:31-96,145-150: one thread per triangle, one launch per ray) by
+// the inverse mapping: every lane owns RT_RPL rays and sweeps ALL triangles, which arrive
+// as three float4 planes (v0|eu, e1|et, e2) staged through LDS in tiles of RT_TILE
+// triangles that all four waves of the workgroup read at wave-uniform addresses
+// (LDS broadcast, no bank conflicts).
+//
+// Arithmetic per (ray, triangle) pair: the full general-origin Moller-Trumbore evaluation
+// in fp32 FMA -- tvec = O - v0, pvec = D x e2, det = e1.pvec, U = tvec.pvec,
+// qvec = tvec x e1, V = D.qvec, T = e2.qvec -- which is the reference's Cramer solve
+// (:59-94) with D = E - S, u = U/det, v = V/det, t = T/det.  The three divisions are
+// replaced by sign-consistent products (a = U*det, b = V*det, c = det*det) so the hot loop
+// is 35 VALU instructions per pair and divides only for the rare pair that passes.
+//
+// The fp32 pass is a conservative FILTER, not the final word: a pair passes when it lies
+// inside the triangle widened by a per-triangle rounding bound (eu, et; see rt_transform.hip).
+// Passing pairs are appended to a short per-ray candidate list in ascending triangle order;
+// rt_exact.hip then re-evaluates only those candidates with the reference's exact fp64
+// arithmetic and comparison rules, so hit indices equal the fp64 result wherever the filter
+// bound holds.  A per-lane running minimum of t (updated only by pairs that are inside by
+// the same bound, i.e. certain hits) prunes candidates that cannot win.
+#include "rt_internal.h"
+
+namespace {
+
+constexpr float RT_INF = __builtin_huge_valf();
+constexpr int OCC_BIT = 0x40000000;
+
+struct Ray {
+    float ox, oy, oz;
+    float dx, dy, dz;
+    float best;      // smallest certain t so far (closest-hit mode)
+    float best_hi;   // pruning threshold: best + its error bound; -inf = ray retired/invalid
+    int cnt;         // candidates pushed so far (OCC_BIT: certainly occluded, any-hit mode)
+};
+
+// One candidate that passed the widened barycentric test.  Rare: a few per ray per sweep.
+template <bool ANYHIT>
+__device__ __forceinline__ void rare_candidate(Ray& r, int32_t* __restrict__ list_slot, int tri,
+                                            float a, float b, float w, float d, float T,
+                                            float eu, float et)
+{
+    const float rd = 1.0f / d;
+    const float t = T * rd;
+    const float terr = et * __builtin_fabsf(rd) + 2e-6f * __builtin_fabsf(t);
+    if (!(t >= -terr) || !(t - terr <= r.best_hi)) return;
+    const int slot = r.cnt & (OCC_BIT - 1);
+    if (slot < RT_LIST_K) list_slot[slot] = tri;
+    r.cnt++;
+    const float margin = eu * __builtin_fabsf(d);
+    const bool certain = (__builtin_fminf(__builtin_fminf(a, b), w) >= margin) && (t >= terr);
+    if (certain) {
+        if (ANYHIT) {
+            r.cnt |= OCC_BIT;
+            r.best_hi = -RT_INF;
+        } else if (t < r.best) {
+            r.best = t;
+            r.best_hi = t + terr;
+        }
+    }
+}
+
+// The 35-instruction pair evaluation.  Returns true when the pair needs the rare path.
+__device__ __forceinline__ bool pair_test(const Ray& r, const float4 V0, const float4 E1,
+                                          const float4 E2, float& a, float& b, float& w,
+                                          float& d, float& T)
+{
+    const float tx = r.ox - V0.x, ty = r.oy - V0.y, tz = r.oz - V0.z;
+    // pvec = D x e2
+    const float px = __builtin_fmaf(r.dy, E2.z, -(r.dz * E2.y));
+    const float py = __builtin_fmaf(r.dz, E2.x, -(r.dx * E2.z));
+    const float pz = __builtin_fmaf(r.dx, E2.y, -(r.dy * E2.x));
+    d = __builtin_fmaf(E1.z, pz, __builtin_fmaf(E1.y, py, E1.x * px));
+    const float U = __builtin_fmaf(tz, pz, __builtin_fmaf(ty, py, tx * px));
+    // qvec = tvec x e1
+    const float qx = __builtin_fmaf(ty, E1.z, -(tz * E1.y));
+    const float qy = __builtin_fmaf(tz, E1.x, -(tx * E1.z));
+    const float qz = __builtin_fmaf(tx, E1.y, -(ty * E1.x));
+    const float V = __builtin_fmaf(r.dz, qz, __builtin_fmaf(r.dy, qy, r.dx * qx));
+    T = __builtin_fmaf(E2.z, qz, __builtin_fmaf(E2.y, qy, E2.x * qx));
+    const float c = d * d;
+    a = U * d;
+    b = V * d;
+    w = (c - a) - b;
+    const float m = __builtin_fminf(__builtin_fminf(a, b), w);      // v_min3_f32
+    return __builtin_fmaf(V0.w, __builtin_fabsf(d), m) > 0.0f;
+}
+
+// Makes a value opaque to the optimiser so that per-ray quantities that happen to be equal
+// in every lane (the shared origin of primary rays) are still carried and used per ray.
+__device__ __forceinline__ float opaque(float x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+enum { MODE_PRIMARY = 0, MODE_RAYS_LINEAR = 1, MODE_RAYS_TILED = 2 };
+
+template <int MODE, bool ANYHIT>
+__global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
+{
+    __shared__ float4 tile[2][3][RT_TILE];     // 24 KiB: double-buffered v0/e1/e2 planes
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    Ray ray[RT_RPL];
+    long slot[RT_RPL];        // index into cnt[] / list[] (band-local pixel or ray number)
+
+    // ---- ray set-up ------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < RT_RPL; ++r) {
+        bool valid;
+        double Sx = 0, Sy = 0, Sz = 0, Ex = 0, Ey = 0, Ez = 0;
+        if (MODE == MODE_RAYS_LINEAR) {
+            const long j = (long)blockIdx.x * RT_RAYS_PER_WG + r * RT_WG + tid;
+            valid = j < A.n_rays;
+            slot[r] = j;
+        } else {
+            // workgroup = RT_TILE_W x RT_TILE_H pixels; wave = (8*RPL) x 8; lane = 8 x 8
+            const int tiles_x = (A.W + RT_TILE_W - 1) / RT_TILE_W;
+            const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+            const int px = txi * RT_TILE_W + (wave & 1) * (8 * RT_RPL) + r * 8 + (lane & 7);
+            const int py = A.y0 + tyi * RT_TILE_H + (wave >> 1) * 8 + (lane >> 3);
+            valid = (px < A.W) && (py < A.y1);
+            const long npix = (long)A.W * (A.y1 - A.y0);
+            slot[r] = (long)blockIdx.y * npix + (long)(py - A.y0) * A.W + px;
+            if (MODE == MODE_PRIMARY) {
+                // driver.c:131-133 with S = origin = 0 (driver.c:121-123)
+                Ex = (double)(px - A.W / 2);
+                Ey = (double)(py - A.H / 2);
+                Ez = A.ez;
+            }
+        }
+        if (MODE != MODE_PRIMARY && valid) {
+            const double* s = A.S + 3 * slot[r];
+            const double* e = A.E + 3 * slot[r];
+            Sx = s[0]; Sy = s[1]; Sz = s[2];
+            Ex = e[0]; Ey = e[1]; Ez = e[2];
+            if (!(Sx == Sx)) valid = false;       // NaN origin marks an unused ray slot
+        }
+        // D is normalised: t scales by |D| for every triangle alike, so the per-ray order of
+        // candidates is unchanged and the per-triangle error bounds need no |D| factor.
+        const double Dx = Ex - Sx, Dy = Ey - Sy, Dz = Ez - Sz;
+        const double inv = 1.0 / __builtin_sqrt(Dx * Dx + Dy * Dy + Dz * Dz);
+        ray[r].ox = opaque((float)Sx);
+        ray[r].oy = opaque((float)Sy);
+        ray[r].oz = opaque((float)Sz);
+        ray[r].dx = (float)(Dx * inv);
+        ray[r].dy = (float)(Dy * inv);
+        ray[r].dz = (float)(Dz * inv);
+        if (!(inv == inv) || inv > 1e300) valid = false;      // zero-length ray hits nothing
+        if (!valid) { ray[r].dx = ray[r].dy = ray[r].dz = 0.0f; ray[r].ox = ray[r].oy = ray[r].oz = 0.0f; }
+        ray[r].best = RT_INF;
+        ray[r].best_hi = valid ? RT_INF : -RT_INF;
+        ray[r].cnt = 0;
+    }
+
+    // ---- tile loop -------------------------------------------------------------------
+    const int ntiles = A.num_tris_padded / RT_TILE;
+    auto stage = [&](int t, int buf) {
+        // 3 planes x RT_TILE float4 = 12 KiB; each wave moves 64 float4 (1 KiB) per plane with
+        // one LDS-DMA instruction: global source per lane, LDS destination wave base + 16*lane.
+        const long g = (long)t * RT_TILE + tid;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(A.v0 + g),
+            (__attribute__((address_space(3))) void*)&tile[buf][0][wave * 64], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(A.e1 + g),
+            (__attribute__((address_space(3))) void*)&tile[buf][1][wave * 64], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(A.e2 + g),
+            (__attribute__((address_space(3))) void*)&tile[buf][2][wave * 64], 16, 0, 0);
+    };
+
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0) & lgkmcnt(0)
+    __syncthreads();
+
+    unsigned long long tiles_done = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+        const float4* __restrict__ pv0 = tile[buf][0];
+        const float4* __restrict__ pe1 = tile[buf][1];
+        const float4* __restrict__ pe2 = tile[buf][2];
+        const int tri0 = t * RT_TILE;
+#pragma unroll 2
+        for (int j = 0; j < RT_TILE; ++j) {
+            const float4 V0 = pv0[j];
+            const float4 E1 = pe1[j];
+            const float4 E2 = pe2[j];
+#pragma unroll
+            for (int r = 0; r < RT_RPL; ++r) {
+                float a, b, w, d, T;
+                if (__builtin_expect(pair_test(ray[r], V0, E1, E2, a, b, w, d, T), 0))
+                    rare_candidate<ANYHIT>(ray[r], A.list + slot[r] * RT_LIST_K, tri0 + j,
+                                           a, b, w, d, T, V0.w, E1.w);
+            }
+        }
+        ++tiles_done;
+        __builtin_amdgcn_s_waitcnt(0);
+        if (ANYHIT) {
+            // retire the workgroup once every ray in it is certainly occluded or unused
+            bool done = true;
+#pragma unroll
+            for (int r = 0; r < RT_RPL; ++r) done = done && (ray[r].best_hi == -RT_INF);
+            if (__syncthreads_and(done)) break;
+        } else {
+            __syncthreads();
+        }
+    }
+
+    // ---- results ---------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < RT_RPL; ++r) {
+        bool in_range;
+        if (MODE == MODE_RAYS_LINEAR) in_range = slot[r] < A.n_rays;
+        else {
+            const int tiles_x = (A.W + RT_TILE_W - 1) / RT_TILE_W;
+            const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+            const int px = txi * RT_TILE_W + (wave & 1) * (8 * RT_RPL) + r * 8 + (lane & 7);
+            const int py = A.y0 + tyi * RT_TILE_H + (wave >> 1) * 8 + (lane >> 3);
+            in_range = (px < A.W) && (py < A.y1);
+        }
+        if (in_range) A.cnt[slot[r]] = ray[r].cnt;
+    }
+    if (A.tests && tid == 0)
+        atomicAdd(A.tests, tiles_done * (unsigned long long)RT_TILE * RT_RAYS_PER_WG);
+}
+
+template <int MODE, bool ANYHIT>
+int launch(const SweepArgs& a, dim3 grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_sweep<MODE, ANYHIT>), grid, dim3(RT_WG), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        rt_set_error("sweep launch failed: %s", hipGetErrorString(e));
+        return RT_E_HIP;
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+int rt_primary_slots(int W, int y0, int y1) { return W * (y1 - y0); }
+
+static int check_common(const SweepArgs& a)
+{
+    if (!a.v0 || !a.e1 || !a.e2 || !a.cnt || !a.list) {
+        rt_set_error("sweep: null buffer");
+        return RT_E_ARG;
+    }
+    if (a.num_tris_padded <= 0 || a.num_tris_padded % RT_TILE != 0 ||
+        a.num_tris > a.num_tris_padded) {
+        rt_set_error("sweep: triangle planes must be padded to a multiple of %d", RT_TILE);
+        return RT_E_ARG;
+    }
+    return RT_OK;
+}
+
+int rt_launch_sweep_primary(const SweepArgs& a, hipStream_t st)
+{
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (a.W <= 0 || a.H <= 0 || a.y1 <= a.y0) {
+        rt_set_error("sweep: empty band");
+        return RT_E_ARG;
+    }
+    const int tiles_x = (a.W + RT_TILE_W - 1) / RT_TILE_W;
+    const int tiles_y = (a.y1 - a.y0 + RT_TILE_H - 1) / RT_TILE_H;
+    return launch<MODE_PRIMARY, false>(a, dim3(tiles_x * tiles_y, 1), st);
+}
+
+int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st)
+{
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (!a.S || !a.E) {
+        rt_set_error("sweep: null ray arrays");
+        return RT_E_ARG;
+    }
+    if (a.W > 0) {      // tiled: n_rays = layers * W * (y1-y0)
+        const long npix = (long)a.W * (a.y1 - a.y0);
+        if (npix <= 0 || a.n_rays % npix != 0) {
+            rt_set_error("sweep: tiled ray count must be a multiple of the band size");
+            return RT_E_ARG;
+        }
+        const int layers = (int)(a.n_rays / npix);
+        const int tiles_x = (a.W + RT_TILE_W - 1) / RT_TILE_W;
+        const int tiles_y = (a.y1 - a.y0 + RT_TILE_H - 1) / RT_TILE_H;
+        dim3 grid(tiles_x * tiles_y, layers);
+        return anyhit ? launch<MODE_RAYS_TILED, true>(a, grid, st)
+                      : launch<MODE_RAYS_TILED, false>(a, grid, st);
+    }
+    if (a.n_rays <= 0) return RT_OK;
+    dim3 grid((a.n_rays + RT_RAYS_PER_WG - 1) / RT_RAYS_PER_WG, 1);
+    return anyhit ? launch<MODE_RAYS_LINEAR, true>(a, grid, st)
+                  : launch<MODE_RAYS_LINEAR, false>(a, grid, st);
+}
