@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the ray-triangle hot path on MI355X.
+
+One "step" = one full frame of the pixel loop (driver.c:126-193) over a synthetic scene that
+is already resident in HBM: per-frame vertex transform + sweep-buffer rebuild, primary
+closest-hit sweep, fp64 confirmation, shading epilogue with its shadow-ray sweeps, and -- for
+N > 1 -- the gather of the row bands to rank 0 over RCCL.  The image is sharded by
+contiguous row bands (strong scaling: the frame is fixed, each GPU holds the full mesh).
+
+Prints ONE JSON line on rank 0.  `value` is whole-job Mrays/s (primary + shadow rays of the
+frame divided by the frame time); ray-triangle tests/s and the fp32 roofline fraction of
+the dominant kernel (the closest-hit sweep, timed with HIP events on its launch stream
+inside the library) ride along, as does a CPU-oracle baseline timed on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+TAN_HALF = math.tan(30 * math.pi / 180)          # driver.c:22,25
+F_TEST = 46.0                                    # fp32 flop per general Moller-Trumbore test
+PEAK_FP32_TFLOPS = 157.3                         # MI355X vector fp32 (256 CU x 256 flop/clk x 2.4 GHz)
+
+WORKLOADS = {
+    # name: (mesh kind, triangles, W, H)
+    "soup1m_4k": ("soup", 1_000_000, 3840, 2160),
+    "mesh100k_4k": ("torus", 100_000, 3840, 2160),
+    "bunny_class_4k": ("sphere", 69_451, 3840, 2160),
+    "teapot_class_480p": ("torus", 6_320, 640, 480),
+    "soup100k_1080p": ("soup", 100_000, 1920, 1080),
+}
+
+
+def make_mesh(kind: str, tris: int):
+    from raytracer_amd import scenes
+    if kind == "soup":
+        return scenes.triangle_soup(tris, seed=12345)
+    if kind == "torus":
+        return scenes.torus(tris)
+    return scenes.sphere(tris)
+
+
+def cpu_baseline(mesh, frame, W, H, budget_s: float = 15.0):
+    """CPU oracle (strict fp64 restatement of the reference's formulas, OpenMP over rows) on
+    a bounded row sample of the same frame; primary rays only."""
+    from oracle import oracle as O
+    from raytracer_amd import kernel
+    X, Y, Z = O.transform(mesh, kernel.frame_matrix(frame, "obmat"))
+    osc = O.Scene(mesh, X, Y, Z)
+    ofr = O.frame_from(frame)
+    import ctypes as C
+    threads = min(O.lib().orc_num_threads(), int(os.environ.get("OMP_NUM_THREADS", "16")), 64)
+    # calibrate on a strip of a narrower image (same per-ray cost), then size the sample
+    cal_w = 16 * threads
+    y_mid = H // 2
+    t0 = time.time()
+    O.lib().orc_render_rows(C.byref(osc.s), C.byref(ofr), cal_w, H, TAN_HALF, y_mid, y_mid + 1, 1, 0,
+                            threads, None, None, None, None)
+    per_ray = max(time.time() - t0, 1e-4) / cal_w          # wall seconds per ray, all threads busy
+    rows = max(min(int(budget_s / (per_ray * W)), H), 1)
+    step = max(H // rows, 1)
+    ys = list(range(step // 2, H, step))[:rows]
+    t0 = time.time()
+    O.lib().orc_render_rows(C.byref(osc.s), C.byref(ofr), W, H, TAN_HALF, ys[0], ys[-1] + 1, step, 0,
+                            threads, None, None, None, None)
+    dt = time.time() - t0
+    rays = len(ys) * W
+    return {
+        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "tests_per_s": rays * mesh.num_tris / dt,
+        "sample": f"{len(ys)} of {H} rows (every {step}th) x {W} primary rays x {mesh.num_tris} triangles, "
+                  f"fp64, {dt:.1f} s",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="soup1m_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import kernel
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; this benchmark has no CPU path", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    kind, tris, W, H = WORKLOADS[args.workload]
+    mesh = make_mesh(kind, tris)
+    frame = kernel.driver_frame(0)
+    obmat = kernel.frame_matrix(frame, "obmat")
+    sc = kernel.Scene(mesh, device=local_rank)
+    y0, y1 = kernel.band(H, world, rank)
+    rows = y1 - y0
+    max_rows = (H + world - 1) // world
+    # outputs live in HBM for the whole run; the gather buffer is padded to the tallest band
+    out = {"hit": torch.empty((rows, W), dtype=torch.int32, device=dev),
+           "rgb8": torch.zeros((max_rows, W, 3), dtype=torch.uint8, device=dev)}
+    gathered = ([torch.empty((max_rows, W, 3), dtype=torch.uint8, device=dev) for _ in range(world)]
+                if (world > 1 and rank == 0) else None)
+    screen = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
+
+    def step():
+        sc.transform(obmat)                       # driver.c:110 on the device-resident mesh
+        sc.render_rows(frame, W, H, TAN_HALF, y0, y1, want=("hit", "rgb8"),
+                       out={"hit": out["hit"], "rgb8": out["rgb8"][:rows]})
+        if world > 1:
+            dist.gather(out["rgb8"], gathered, dst=0)        # RCCL over xGMI
+            if rank == 0:
+                for r in range(world):
+                    a, b = kernel.band(H, world, r)
+                    sc.place_rows(gathered[r][: b - a], W, H, a, b, screen)
+        else:
+            sc.place_rows(out["rgb8"][:rows], W, H, y0, y1, screen)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel.profile_enable(True)
+    kernel.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = kernel.profile_get()
+    kernel.profile_enable(False)
+
+    stats = torch.tensor([dt, float(prof.rays_primary), float(prof.rays_shadow), float(prof.sweep_tests),
+                          float(prof.shadow_tests), prof.sweep_ms, float(prof.sweep_launches),
+                          prof.shadow_ms, float(prof.exact_candidates), float(prof.exact_overflow)],
+                         dtype=torch.float64, device=dev)
+    tmax = stats.clone()
+    tsum = stats.clone()
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        wall = tmax[0].item()
+        steps = args.steps
+        rays_p, rays_s = tsum[1].item() / steps, tsum[2].item() / steps
+        tests = (tsum[3].item() + tsum[4].item()) / steps
+        hit_frac = float((out["hit"] >= 0).float().mean().item())
+        # roofline of the dominant kernel: rank 0's closest-hit sweep launches
+        sweep_ms_avg = prof.sweep_ms / max(prof.sweep_launches, 1)
+        tests_per_launch = prof.sweep_tests / max(prof.sweep_launches, 1)
+        achieved = F_TEST * tests_per_launch / (sweep_ms_avg * 1e-3) / 1e12 if sweep_ms_avg > 0 else 0.0
+        res = {
+            "metric": "Mrays/s and ray-tri tests/s (% fp32 peak) at 1/2/4/8 MI355X vs host-CPU ref",
+            "value": (rays_p + rays_s) / (wall / steps) / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": wall / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "mesh": mesh.name, "triangles": mesh.num_tris,
+                       "width": W, "height": H, "lights": frame.num_lights,
+                       "sharding": f"{world} row band(s), RCCL gather to rank 0" if world > 1 else "single GPU"},
+            "primary_mrays_per_s": rays_p / (wall / steps) / 1e6,
+            "rays_per_frame": {"primary": rays_p, "shadow": rays_s},
+            "tests_per_s": tests / (wall / steps),
+            "pct_fp32_peak_whole_frame": 100.0 * F_TEST * tests / (wall / steps) / 1e12 / (PEAK_FP32_TFLOPS * world),
+            "hit_fraction_rank0": hit_frac,
+            "fp64_confirmations_per_frame": tsum[8].item() / steps,
+            "overflow_rays_per_frame": tsum[9].item() / steps,
+            "roofline": {
+                "bound": "valu-fp32", "kernel": "k_sweep<primary,closest>",
+                "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_TFLOPS,
+                "avg_launch_ms": sweep_ms_avg, "tests_per_launch": tests_per_launch,
+                "flop_per_test": F_TEST, "traffic": None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(mesh, frame, W, H, args.cpu_budget)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

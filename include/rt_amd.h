@@ -168,8 +168,11 @@ typedef struct rt_profile {
     uint64_t rays_shadow;
     uint64_t exact_candidates;  /* fp64 confirmations */
     uint64_t exact_overflow;    /* rays that fell back to the full fp64 sweep */
+    uint64_t rays_live;         /* generic-ray launches: rays in use (unused slots excluded) */
 } rt_profile;
-int rt_profile_enable(int on);     /* wraps sweep launches in HIP events (adds a sync each) */
+int rt_profile_enable(int on);     /* wraps sweep launches in HIP events and reads the device
+                                      counters back (adds a sync per launch); the ray and
+                                      candidate counts above are only collected while on */
 int rt_profile_reset(void);
 int rt_profile_get(rt_profile* out);
 

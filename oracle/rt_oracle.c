@@ -579,43 +579,44 @@ long orc_render_rows(const OrcScene* sc, const OrcFrame* f, int W, int H, double
                      int32_t* hit, double* tuv, double* argb, uint8_t* rgb8)
 {
     long shadow_total = 0;
-    int y_pix;
     if (ystep < 1) ystep = 1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #else
     (void)nthreads;
 #endif
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : shadow_total)
-    for (y_pix = y0; y_pix < y1; y_pix += ystep) {
-        int x_pix;
-        for (x_pix = 0; x_pix < W; x_pix++) {
-            double origin[3] = {0, 0, 0}, screen_pt[3];              /* :121-123 */
-            double uv[2], point[3], normal[3], col[3], t = 0;
-            long shadows = 0;
-            size_t o = (size_t)y_pix * W + x_pix;
-            screen_pt[0] = x_pix - W / 2;                            /* :131-133, integer W/2 */
-            screen_pt[1] = y_pix - H / 2;
-            screen_pt[2] = (W / 2) / tan_half;
-            int s = intersect_all_t(sc, origin, screen_pt, uv, point, &t);
-            if (hit) hit[o] = s;
-            if (s != -1 && tuv) { tuv[3 * o] = t; tuv[3 * o + 1] = uv[0]; tuv[3 * o + 2] = uv[1]; }
-            if (!shade) continue;
-            if (s == -1) {
-                col[0] = col[1] = col[2] = 0.5;                      /* :136-139 */
-            } else {
-                double Ka[3], Kd[3], Ks[3];
-                orc_interpolate_normal(sc, s, uv, f->obinv, normal); /* :142 */
-                select_material(sc, s, uv, Ka, Kd, Ks);
-                orc_light_model(sc, f, Ka, Kd, Ks, origin, point, normal, col, &shadows);
-            }
-            shadow_total += shadows;
-            if (argb) { argb[3 * o] = col[0]; argb[3 * o + 1] = col[1]; argb[3 * o + 2] = col[2]; }
-            if (rgb8) {
-                rgb8[3 * o] = orc_quantize(col[0]);
-                rgb8[3 * o + 1] = orc_quantize(col[1]);
-                rgb8[3 * o + 2] = orc_quantize(col[2]);
-            }
+    const int nrows = (y1 > y0) ? (y1 - y0 + ystep - 1) / ystep : 0;
+    const long total = (long)nrows * W;
+    long k;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : shadow_total)
+    for (k = 0; k < total; k++) {
+        const int y_pix = y0 + (int)(k / W) * ystep;
+        const int x_pix = (int)(k % W);
+        double origin[3] = {0, 0, 0}, screen_pt[3];              /* :121-123 */
+        double uv[2], point[3], normal[3], col[3], t = 0;
+        long shadows = 0;
+        size_t o = (size_t)y_pix * W + x_pix;
+        screen_pt[0] = x_pix - W / 2;                            /* :131-133, integer W/2 */
+        screen_pt[1] = y_pix - H / 2;
+        screen_pt[2] = (W / 2) / tan_half;
+        int s = intersect_all_t(sc, origin, screen_pt, uv, point, &t);
+        if (hit) hit[o] = s;
+        if (s != -1 && tuv) { tuv[3 * o] = t; tuv[3 * o + 1] = uv[0]; tuv[3 * o + 2] = uv[1]; }
+        if (!shade) continue;
+        if (s == -1) {
+            col[0] = col[1] = col[2] = 0.5;                      /* :136-139 */
+        } else {
+            double Ka[3], Kd[3], Ks[3];
+            orc_interpolate_normal(sc, s, uv, f->obinv, normal); /* :142 */
+            select_material(sc, s, uv, Ka, Kd, Ks);
+            orc_light_model(sc, f, Ka, Kd, Ks, origin, point, normal, col, &shadows);
+        }
+        shadow_total += shadows;
+        if (argb) { argb[3 * o] = col[0]; argb[3 * o + 1] = col[1]; argb[3 * o + 2] = col[2]; }
+        if (rgb8) {
+            rgb8[3 * o] = orc_quantize(col[0]);
+            rgb8[3 * o + 1] = orc_quantize(col[1]);
+            rgb8[3 * o + 2] = orc_quantize(col[2]);
         }
     }
     return shadow_total;

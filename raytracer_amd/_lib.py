@@ -47,6 +47,7 @@ class RtProfile(C.Structure):
         ("rays_shadow", C.c_uint64),
         ("exact_candidates", C.c_uint64),
         ("exact_overflow", C.c_uint64),
+        ("rays_live", C.c_uint64),
     ]
 
 

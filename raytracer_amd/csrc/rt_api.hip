@@ -470,14 +470,16 @@ static int workspaces(rt_scene* sc, size_t slots)
 
 static int fetch_counters(rt_scene* sc, bool sync_always)
 {
-    // counters[0] = overflowed rays, [1] = fp64 candidates evaluated, [2..3] = pair counter
+    // counters[0] = overflowed rays, [1] = fp64 candidates evaluated, [2..3] = pair counter,
+    // [4] = live rays of a generic-ray launch
     RtGlobal& g = rt_g();
     if (!g.profiling && !sync_always) return RT_OK;
-    int c[4] = {0, 0, 0, 0};
+    int c[5] = {0, 0, 0, 0, 0};
     RT_HIP(hipMemcpyAsync(c, sc->ws_counters.p, sizeof c, hipMemcpyDeviceToHost, g.stream));
     RT_HIP(hipStreamSynchronize(g.stream));
     g.prof.exact_overflow += (uint64_t)c[0];
     g.prof.exact_candidates += (uint64_t)c[1];
+    g.prof.rays_live += (uint64_t)c[4];
     return RT_OK;
 }
 
@@ -539,15 +541,18 @@ static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E
         : (uint64_t)((n + RT_RAYS_PER_WG - 1) / RT_RAYS_PER_WG);
     const uint64_t tests = wgs * RT_RAYS_PER_WG * (uint64_t)sc->num_tris_padded;
     RT_TRY(timed_sweep([&] { return rt_launch_sweep_rays(a, anyhit, st); }, anyhit, tests, a.tests));
-    if (anyhit) g.prof.rays_shadow += (uint64_t)n;
-    else g.prof.rays_primary += (uint64_t)n;
     const ExactScene es = exact_of(sc);
     int* counters = sc->ws_counters.as<int>();
     RT_TRY(rt_launch_resolve_rays(es, n, S, E, a.cnt, a.list, anyhit, hit, tuv, point, occ,
                                   sc->ws_ovf.as<int32_t>(), counters, st));
     RT_TRY(rt_launch_overflow_rays(es, S, E, sc->ws_ovf.as<int32_t>(), counters, anyhit, hit, tuv,
                                    point, occ, st));
-    RT_TRY(fetch_counters(sc, false));
+    {
+        const uint64_t before = g.prof.rays_live;
+        RT_TRY(fetch_counters(sc, false));
+        if (anyhit) g.prof.rays_shadow += g.prof.rays_live - before;
+        else g.prof.rays_primary += g.prof.rays_live - before;
+    }
     return RT_OK;
 }
 

@@ -146,10 +146,13 @@ k_resolve_rays(ExactScene es, int n, const double* __restrict__ Sa, const double
                uint8_t* __restrict__ occ_out, int32_t* __restrict__ ovf, int* __restrict__ counters)
 {
     const long p = (long)blockIdx.x * RT_WG + threadIdx.x;
+    const bool live = p < n && (Sa[3 * p] == Sa[3 * p]);       // NaN origin = unused ray slot
+    const unsigned long long live_mask = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && live_mask) atomicAdd(&counters[4], __popcll(live_mask));
     if (p >= n) return;
     const double S[3] = {Sa[3 * p], Sa[3 * p + 1], Sa[3 * p + 2]};
     const double E[3] = {Ea[3 * p], Ea[3 * p + 1], Ea[3 * p + 2]};
-    if (!(S[0] == S[0])) {            // unused ray slot
+    if (!live) {
         if (ANYHIT) occ_out[p] = 0; else hit[p] = -1;
         return;
     }
