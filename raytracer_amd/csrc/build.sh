@@ -5,16 +5,21 @@
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
 root="$(cd "$here/../.." && pwd)"
-out="$root/raytracer_amd/librt_amd.so"
+out="${RT_AMD_OUT:-$root/raytracer_amd/librt_amd.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(-O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -I"$root/include" -I"$here" -Wall -Wno-unused-value)
 objs=()
-mkdir -p "$here/build"
+bdir="${RT_AMD_BUILD_DIR:-$here/build}"
+mkdir -p "$bdir"
 for src in rt_sweep.hip rt_exact.hip rt_transform.hip rt_shade.hip rt_api.hip rt_host.cpp rt_obj.cpp; do
-  obj="$here/build/${src%.*}.o"
+  obj="$bdir/${src%.*}.o"
   if [ ! -f "$obj" ] || [ "$here/$src" -nt "$obj" ] || [ "$here/rt_internal.h" -nt "$obj" ] || [ "$root/include/rt_amd.h" -nt "$obj" ]; then
     echo "hipcc $src"
-    "$HIPCC" "${FLAGS[@]}" ${EXTRA_FLAGS:-} -c "$here/$src" -o "$obj"
+    extra=()
+    # The sweep must stay scalar fp32: SLP-packing it into v_pk_* costs shuffles and doubles the
+    # issue time of each packed instruction on gfx950, a net loss for this loop.
+    [ "$src" = rt_sweep.hip ] && extra=(-fno-slp-vectorize)
+    "$HIPCC" "${FLAGS[@]}" "${extra[@]}" ${EXTRA_FLAGS:-} -c "$here/$src" -o "$obj"
   fi
   objs+=("$obj")
 done

@@ -34,8 +34,14 @@ void rt_set_error(const char* fmt, ...);
 
 // ---------------------------------------------------------------- tunables
 constexpr int RT_WG = 256;          // threads per workgroup of every kernel here (4 waves)
-constexpr int RT_TILE = 256;        // triangles per LDS tile of the sweep
-constexpr int RT_RPL = 2;           // rays per lane in the sweep
+#ifndef RT_TILE_TRIS
+#define RT_TILE_TRIS 256
+#endif
+#ifndef RT_RAYS_PER_LANE
+#define RT_RAYS_PER_LANE 2
+#endif
+constexpr int RT_TILE = RT_TILE_TRIS;      // triangles per LDS tile of the sweep
+constexpr int RT_RPL = RT_RAYS_PER_LANE;   // rays per lane in the sweep
 constexpr int RT_LIST_K = 16;       // candidate slots per ray handed to the fp64 confirmation
 constexpr int RT_TILE_W = 16 * RT_RPL;   // pixel tile of one workgroup: 2x2 waves of (8*RPL)x8
 constexpr int RT_TILE_H = 16;
