@@ -233,13 +233,13 @@ def to_obj_text(mesh: Mesh, fmt: int = 3, quads: bool = False) -> str:
     consecutive triangle pairs (a,b,c),(a,c,d) are merged back into `f a b c d`."""
     out = io.StringIO()
     for i in range(1, mesh.num_v + 1):
-        out.write(f"v {mesh.x[i]!r} {mesh.y[i]!r} {mesh.z[i]!r}\n")
+        out.write(f"v {float(mesh.x[i])!r} {float(mesh.y[i])!r} {float(mesh.z[i])!r}\n")
     if fmt in (2, 3):
         for i in range(1, mesh.num_vt + 1):
-            out.write(f"vt {mesh.u[i]!r} {mesh.v[i]!r}\n")
+            out.write(f"vt {float(mesh.u[i])!r} {float(mesh.v[i])!r}\n")
     if fmt in (3, 4):
         for i in range(1, mesh.num_vn + 1):
-            out.write(f"vn {mesh.xn[i]!r} {mesh.yn[i]!r} {mesh.zn[i]!r}\n")
+            out.write(f"vn {float(mesh.xn[i])!r} {float(mesh.yn[i])!r} {float(mesh.zn[i])!r}\n")
 
     def ref(k, which):
         v = (mesh.A, mesh.B, mesh.C)[which][k]

@@ -186,3 +186,78 @@ def test_legacy_kernel_h_api():
     s = kernel.intersect_all_triangles_device(S, E, uv, point, tris, x, y, z, mesh.num_tris)
     idx, t, ouv, op = O.intersect(osc2, S, E)
     assert s == idx and idx != -1 and np.array_equal(uv, ouv)
+
+
+GOLDEN = {
+    "frame_soup400_64x48_f3": (lambda: scenes.triangle_soup(400, seed=21), 3, 64, 48),
+    "frame_torus600_80x60_f11": (lambda: scenes.with_materials(scenes.torus(600), num_mats=3, seed=5), 11, 80, 60),
+    "frame_sphere300_48x64_f40": (lambda: scenes.sphere(300), 40, 48, 64),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_golden_frames(name):
+    """Committed fixtures (tests/golden/make_golden.py): the GPU box has no reference checkout
+    and needs no oracle run for these."""
+    import os
+    make, frame_no, W, H = GOLDEN[name]
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    mesh = make()
+    fr = kernel.driver_frame(frame_no)
+    sc = kernel.Scene(mesh)
+    sc.transform(kernel.frame_matrix(fr, "obmat"))
+    out = sc.render_rows(fr, W, H, TAN_HALF)
+    hit = out["hit"].cpu().numpy()
+    assert np.array_equal(hit, g["hit"])
+    m = g["hit"] >= 0
+    assert np.array_equal(out["tuv"].cpu().numpy()[m], g["tuv"][m])
+    assert np.abs(out["rgb8"].cpu().numpy().astype(int) - g["rgb8"].astype(int)).max() <= 1
+    assert np.abs(out["argb"].cpu().numpy() - g["argb"]).max() < 1e-9
+    screen = sc.place_rows(out["rgb8"], W, H, 0, H).cpu().numpy()
+    assert np.array_equal(screen, O.place_pixels(out["rgb8"].cpu().numpy()))
+    sc.close()
+
+
+def test_obj_file_to_frame(tmp_path):
+    """Loader -> scene -> frame: rt_obj_load + rt_scene_set_obj against the oracle fed by the
+    Python restatement of the parser."""
+    from oracle import obj_oracle
+    from raytracer_amd import _lib
+    src = scenes.with_materials(scenes.torus(300, normalize=False), num_mats=2, unassigned_every=4)
+    (tmp_path / "m.mtl").write_text("".join(
+        f"newmtl m{k}\nKa {' '.join(repr(float(v)) for v in src.Ka[k])}\n"
+        f"Kd {' '.join(repr(float(v)) for v in src.Kd[k])}\nKs {' '.join(repr(float(v)) for v in src.Ks[k])}\n"
+        for k in range(2)))
+    lines = ["mtllib m.mtl"] + scenes.to_obj_text(src, fmt=4, quads=False).splitlines()
+    body, cur = [], None
+    fi = 0
+    for ln in lines:
+        if ln.startswith("f "):
+            m = int(src.mtl[fi]); fi += 1
+            if m >= 0 and m != cur:
+                body.append(f"usemtl m{m}"); cur = m
+        body.append(ln)
+    (tmp_path / "m.obj").write_text("\n".join(body) + "\n")
+    ref = obj_oracle.load(str(tmp_path / "m.obj"))
+    mesh = scenes.Mesh(**{k: np.ascontiguousarray(ref[k]) for k in
+                          ("x", "y", "z", "xn", "yn", "zn", "A", "B", "C", "An", "Bn", "Cn")},
+                       mtl=np.ascontiguousarray(ref["mtl"]), Ka=ref["Ka"], Kd=ref["Kd"], Ks=ref["Ks"])
+    fr = kernel.driver_frame(9)
+    W, H = 72, 54
+    X, Y, Z = O.transform(mesh, kernel.frame_matrix(fr, "obmat"))
+    want = O.render_rows(O.Scene(mesh, X, Y, Z), O.frame_from(fr), W, H, TAN_HALF)
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.rt_obj_load(str(tmp_path / "m.obj").encode(), C.byref(h)) == 0
+    sc = kernel.Scene()
+    _lib.check(lib.rt_scene_set_obj(sc.h, h), "rt_scene_set_obj")
+    v = _lib.RtObjView()
+    lib.rt_obj_get(h, C.byref(v))
+    assert v.pinned == 1                       # page-locked SoA buffers when a GPU is present
+    sc.transform(kernel.frame_matrix(fr, "obmat"))
+    out = sc.render_rows(fr, W, H, TAN_HALF)
+    assert np.array_equal(out["hit"].cpu().numpy(), want["hit"])
+    assert np.abs(out["rgb8"].cpu().numpy().astype(int) - want["rgb8"].astype(int)).max() <= 1
+    assert (want["hit"] >= 0).sum() > 100
+    lib.rt_obj_free(h)
+    sc.close()

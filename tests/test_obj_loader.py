@@ -1,0 +1,176 @@
+"""The C++ loader (rt_obj_load) against the Python restatement of obj_reader.c and against
+hand-written expectations.  No GPU needed: the loader is host code."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import obj_oracle
+from raytracer_amd import _lib, scenes
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_view(path):
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.rt_obj_load(path.encode(), C.byref(h))
+    if rc != 0:
+        return rc, lib.rt_last_error().decode()
+    v = _lib.RtObjView()
+    assert lib.rt_obj_get(h, C.byref(v)) == 0
+    def arr(p, n, dt):
+        return np.ctypeslib.as_array(p, shape=(n,)).astype(dt).copy() if n else np.zeros(0, dt)
+    out = {"num_v": v.num_v, "num_vn": v.num_vn, "num_vt": v.num_vt, "num_tris": v.num_tris,
+           "num_mats": v.num_mats, "pinned": v.pinned}
+    for k in ("x", "y", "z"):
+        out[k] = arr(getattr(v, k), v.num_v + 1, np.float64)
+    for k in ("xn", "yn", "zn"):
+        out[k] = arr(getattr(v, k), v.num_vn + 1, np.float64)
+    for k in ("u", "v"):
+        out[k] = arr(getattr(v, k), v.num_vt + 1, np.float64)
+    for k in ("A", "B", "C", "An", "Bn", "Cn", "At", "Bt", "Ct", "mtl"):
+        out[k] = arr(getattr(v, k), v.num_tris, np.int32)
+    for k in ("Ka", "Kd", "Ks"):
+        out[k] = arr(getattr(v, k), 3 * v.num_mats, np.float64).reshape(-1, 3)
+    lib.rt_obj_free(h)
+    return 0, out
+
+
+def _same(got, ref, tex=True, nrm=True):
+    keys = ["x", "y", "z", "xn", "yn", "zn", "A", "B", "C", "An", "Bn", "Cn", "mtl", "Ka", "Kd", "Ks"]
+    if tex:
+        keys += ["u", "v", "At", "Bt", "Ct"]
+    for k in keys:
+        assert np.array_equal(got[k], ref[k]), k
+
+
+QUAD = "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\n"
+
+
+@pytest.mark.parametrize("fmt,face", [
+    (1, "f 1 2 3 4\n"),
+    (2, "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1 2/2 3/3 4/4\n"),
+    (3, "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 1\nvn 0 0 2\nvn 0 0 3\nvn 0 0 4\nf 1/1/1 2/2/2 3/3/3 4/4/4\n"),
+    (4, "vn 0 0 1\nvn 0 0 2\nvn 0 0 3\nvn 0 0 4\nf 1//1 2//2 3//3 4//4\n"),
+])
+def test_quad_split_in_all_four_formats(tmp_path, fmt, face):
+    p = tmp_path / "q.obj"
+    p.write_text(QUAD + face)
+    rc, got = load_view(str(p))
+    assert rc == 0
+    # obj_reader.c:167-231 (and the survey's recorded run of the reference): (1,2,3) + (1,3,4)
+    assert got["num_tris"] == 2
+    assert (got["A"].tolist(), got["B"].tolist(), got["C"].tolist()) == ([1, 1], [2, 3], [3, 4])
+    if fmt in (1, 2):       # one synthesised, un-normalised face normal AB x AC shared by both halves
+        assert got["num_vn"] == 1
+        assert got["An"].tolist() == got["Bn"].tolist() == got["Cn"].tolist() == [1, 1]
+        assert (got["xn"][1], got["yn"][1], got["zn"][1]) == (0.0, 0.0, 1.0)
+    else:
+        assert got["An"].tolist() == [1, 1] and got["Bn"].tolist() == [2, 3] and got["Cn"].tolist() == [3, 4]
+    if fmt in (2, 3):
+        assert got["At"].tolist() == [1, 1] and got["Bt"].tolist() == [2, 3] and got["Ct"].tolist() == [3, 4]
+    assert got["mtl"].tolist() == [-1, -1]                         # no usemtl seen, obj_reader.c:18
+    # centre + scale: unit square -> 15 units, centred (obj_reader.c:239-289)
+    assert got["x"][1:].tolist() == [-7.5, 7.5, 7.5, -7.5] and got["y"][1:].tolist() == [-7.5, -7.5, 7.5, 7.5]
+    _same(got, obj_oracle.load(str(p)), tex=fmt in (2, 3))
+
+
+def test_face_normal_uses_pre_scale_coordinates(tmp_path):
+    p = tmp_path / "n.obj"
+    p.write_text("v 0 0 0\nv 2 0 0\nv 0 3 0\nv 0 0 40\nf 1 2 3\nf 1 2 4\n")
+    rc, got = load_view(str(p))
+    assert rc == 0 and got["num_vn"] == 2
+    assert (got["xn"][1], got["yn"][1], got["zn"][1]) == (0.0, 0.0, 6.0)     # (2,0,0) x (0,3,0), raw units
+    assert (got["xn"][2], got["yn"][2], got["zn"][2]) == (0.0, -80.0, 0.0)
+    _same(got, obj_oracle.load(str(p)), tex=False)
+
+
+def test_more_than_four_vertices_is_an_error(tmp_path):
+    p = tmp_path / "p.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 2 0\nf 1 2 3 4 5\n")
+    rc, msg = load_view(str(p))
+    assert rc == -4 and "more than 4 vertices" in msg               # obj_reader.c:500-505 exits there
+    with pytest.raises(obj_oracle.ObjError):
+        obj_oracle.load(str(p))
+
+
+def test_missing_file_and_bad_index(tmp_path):
+    rc, msg = load_view(str(tmp_path / "absent.obj"))
+    assert rc == -4 and "can't open file" in msg                    # obj_reader.c:468-472
+    p = tmp_path / "neg.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf -3 -2 -1\n")
+    rc, msg = load_view(str(p))
+    assert rc == -4 and "relative indices" in msg
+
+
+def test_materials_comments_groups_and_mixed_faces(tmp_path):
+    (tmp_path / "m.mtl").write_text(
+        "# materials\nnewmtl red\nKa 0.1 0.2 0.3\nKd 0.9 0.1 0.1\nKs 0.5 0.5 0.5\nNs 96.0\nillum 2\nd 1.0\n"
+        "newmtl plain\nTf 1 1 1\nNi 1.5\nmap_bump bump.png\n"
+        "newmtl blue\nKd 0 0 1\nKe 0 0 0\nTr 0.0\n")
+    (tmp_path / "m.obj").write_text(
+        "# a comment line with f 1 2 3 inside\nmtllib m.mtl\no thing\ng grp\ns off\n"
+        "v 0 0 0 1.0\nv 4 0 0\nv 4 2 0\nv 0 2 0\nv 2 1 3\n"
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvt 0.5 0.5\n"
+        "f 1/1 2/2 5/5\n"                    # before any usemtl: mtl -1
+        "usemtl blue\nf 2/2 3/3 5/5\n"
+        "usemtl nosuchmaterial\nf 3/3 4/4 5/5\n"     # unknown name keeps the current one
+        "usemtl red\nf 4/4 1/1 5/5\nf 1/1 4/4 3/3 2/2\n")
+    rc, got = load_view(str(tmp_path / "m.obj"))
+    assert rc == 0
+    assert got["num_mats"] == 3 and got["num_tris"] == 6
+    assert got["mtl"].tolist() == [-1, 2, 2, 0, 0, 0]
+    assert got["Ka"][0].tolist() == [0.1, 0.2, 0.3] and got["Kd"][2].tolist() == [0.0, 0.0, 1.0]
+    assert got["Ka"][1].tolist() == [1.0, 1.0, 1.0]                 # defaults, obj_reader.c:296-298
+    assert got["num_vn"] == 5                                       # one synthesised normal per FACE
+    assert got["An"].tolist() == [1, 2, 3, 4, 5, 5]
+    _same(got, obj_oracle.load(str(tmp_path / "m.obj")))
+
+
+@pytest.mark.parametrize("fmt,quads", [(1, True), (3, False), (3, True), (4, True)])
+def test_generated_mesh_roundtrip(tmp_path, fmt, quads):
+    m = scenes.torus(120, with_uv=True, normalize=False)
+    p = tmp_path / "t.obj"
+    p.write_text(scenes.to_obj_text(m, fmt=fmt, quads=quads))
+    rc, got = load_view(str(p))
+    assert rc == 0 and got["num_tris"] == m.num_tris and got["num_v"] == m.num_v
+    assert np.array_equal(got["A"], m.A) and np.array_equal(got["B"], m.B) and np.array_equal(got["C"], m.C)
+    ref = obj_oracle.load(str(p))
+    _same(got, ref, tex=fmt in (2, 3))
+    m2 = m.copy()
+    scenes.center_and_scale(m2)
+    assert np.array_equal(got["x"], m2.x) and np.array_equal(got["y"], m2.y) and np.array_equal(got["z"], m2.z)
+
+
+def test_golden_obj_fixtures():
+    """tests/golden/*.obj with expected arrays produced by tests/golden/make_golden.py."""
+    import json
+    names = sorted(f for f in os.listdir(GOLD) if f.endswith(".obj"))
+    assert names, "no golden obj fixtures"
+    for name in names:
+        exp = json.load(open(os.path.join(GOLD, name[:-4] + ".expected.json")))
+        rc, got = load_view(os.path.join(GOLD, name))
+        assert rc == 0, name
+        for k, val in exp.items():
+            a = np.asarray(val)
+            if a.dtype.kind == "f":
+                assert np.array_equal(got[k].ravel(), a.ravel()), (name, k)
+            else:
+                assert got[k].ravel().tolist() == a.ravel().tolist(), (name, k)
+
+
+def test_image_maps_ppm_and_bmp(tmp_path):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, size=(3, 4, 3), dtype=np.uint8)
+    (tmp_path / "tex.ppm").write_bytes(b"P6\n# c\n4 3\n255\n" + img.tobytes())
+    (tmp_path / "t.mtl").write_text("newmtl a\nmap_Kd tex.ppm\nmap_Ka missing.png\n")
+    (tmp_path / "t.obj").write_text("mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\n")
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.rt_obj_load(str(tmp_path / "t.obj").encode(), C.byref(h)) == 0
+    v = _lib.RtObjView()
+    lib.rt_obj_get(h, C.byref(v))
+    assert v.map_Kd[0] == 0 and v.map_Ka[0] == -1 and v.map_Ks[0] == -1   # failed decode keeps the constant
+    lib.rt_obj_free(h)
