@@ -139,7 +139,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->pv0,
                       &sc->pe1, &sc->pe2, &sc->scratch_max, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
-                      &sc->ws_occ, &sc->ws_shcnt, &sc->ws_shlist};
+                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : sc->tex_data) b.release();
     delete sc;
@@ -452,6 +452,7 @@ static int timed_sweep(F&& launch, bool shadow, uint64_t tests_if_closest,
     if (shadow) {
         unsigned long long t = 0;
         RT_HIP(hipMemcpy(&t, dev_tests, sizeof t, hipMemcpyDeviceToHost));
+        RT_HIP(hipMemset(dev_tests, 0, sizeof t));      // the counter restarts for the next range
         g.prof.shadow_ms += ms; g.prof.shadow_launches++; g.prof.shadow_tests += t;
     } else {
         g.prof.sweep_ms += ms; g.prof.sweep_launches++; g.prof.sweep_tests += tests_if_closest;
@@ -503,6 +504,7 @@ extern "C" int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int
     a.ez = (double)(W / 2) / tan_half;
     a.cnt = sc->ws_cnt.as<int32_t>(); a.list = sc->ws_list.as<int32_t>();
     a.tests = nullptr;
+    a.tri_begin = 0; a.tri_end = sc->num_tris_padded;
     const int tiles_x = (W + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (y1 - y0 + RT_TILE_H - 1) / RT_TILE_H;
     const uint64_t tests = (uint64_t)tiles_x * tiles_y * RT_RAYS_PER_WG * (uint64_t)sc->num_tris_padded;
     RT_TRY(timed_sweep([&] { return rt_launch_sweep_primary(a, st); }, false, tests, nullptr));
@@ -535,12 +537,48 @@ static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E
     a.n_rays = n; a.S = S; a.E = E;
     a.cnt = sc->ws_cnt.as<int32_t>(); a.list = sc->ws_list.as<int32_t>();
     a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
-    const uint64_t wgs = tiledW > 0
-        ? (uint64_t)((tiledW + RT_TILE_W - 1) / RT_TILE_W) * ((y1 - y0 + RT_TILE_H - 1) / RT_TILE_H) *
-              (uint64_t)(n / ((size_t)tiledW * (y1 - y0)))
-        : (uint64_t)((n + RT_RAYS_PER_WG - 1) / RT_RAYS_PER_WG);
-    const uint64_t tests = wgs * RT_RAYS_PER_WG * (uint64_t)sc->num_tris_padded;
-    RT_TRY(timed_sweep([&] { return rt_launch_sweep_rays(a, anyhit, st); }, anyhit, tests, a.tests));
+    const int np = sc->num_tris_padded;
+    if (!anyhit) {
+        a.tri_begin = 0; a.tri_end = np;
+        const uint64_t wgs = (uint64_t)((n + RT_RAYS_PER_WG - 1) / RT_RAYS_PER_WG);
+        RT_TRY(timed_sweep([&] { return rt_launch_sweep_rays(a, false, st); }, false,
+                           wgs * RT_RAYS_PER_WG * (uint64_t)np, a.tests));
+    } else {
+        // Any-hit: triangle ranges of doubling length, survivors compacted between ranges.
+        // A ray's cost becomes ~ the index of its first certain occluder, not the mesh size.
+        RT_TRY(sc->ws_act0.reserve(sizeof(int32_t) * (size_t)n));
+        RT_TRY(sc->ws_act1.reserve(sizeof(int32_t) * (size_t)n));
+        int32_t* act[2] = {sc->ws_act0.as<int32_t>(), sc->ws_act1.as<int32_t>()};
+        int* live_count = sc->ws_counters.as<int>() + 8;        // counters[8]
+        int first = np / 64;
+        first = ((first + RT_TILE - 1) / RT_TILE) * RT_TILE;
+        if (first < 16 * RT_TILE) first = 16 * RT_TILE;
+        int begin = 0, len = first, live = n, cur = 0;
+        bool indexed = false;
+        while (begin < np && live > 0) {
+            int end = begin + len;
+            if (end > np || np - end < len / 2) end = np;
+            a.tri_begin = begin; a.tri_end = end;
+            a.resume = begin > 0;
+            a.active = indexed ? act[cur] : nullptr;
+            a.n_rays = indexed ? live : n;
+            RT_TRY(timed_sweep([&] { return rt_launch_sweep_rays(a, true, st); }, true, 0, a.tests));
+            if (getenv("RT_AMD_TRACE_PASSES"))
+                fprintf(stderr, "rt_amd: any-hit range [%d,%d) over %d rays\n", begin, end,
+                        indexed ? live : n);
+            begin = end;
+            if (begin >= np) break;
+            // compact the survivors (first time from the full range, then from the last list)
+            RT_HIP(hipMemsetAsync(live_count, 0, sizeof(int), st));
+            RT_TRY(rt_launch_compact(a.cnt, indexed ? act[cur] : nullptr, indexed ? live : n,
+                                     act[cur ^ 1], live_count, st));
+            RT_HIP(hipMemcpyAsync(&live, live_count, sizeof(int), hipMemcpyDeviceToHost, st));
+            RT_HIP(hipStreamSynchronize(st));
+            cur ^= 1;
+            indexed = true;
+            len *= 2;
+        }
+    }
     const ExactScene es = exact_of(sc);
     int* counters = sc->ws_counters.as<int>();
     RT_TRY(rt_launch_resolve_rays(es, n, S, E, a.cnt, a.list, anyhit, hit, tuv, point, occ,

@@ -17,7 +17,6 @@
 
 namespace {
 
-constexpr int OCC_BIT = 0x40000000;
 
 // triangle_intersection.cu:6-11
 __device__ __forceinline__ double det_2x2(double a0, double a1, double b0, double b1)
@@ -96,11 +95,11 @@ __device__ __forceinline__ bool confirm_list(const ExactScene& es, const double 
     best.idx = -1;
     best.u = best.v = 0;
     occluded = false;
-    if (ANYHIT && (cnt & OCC_BIT)) {
+    if (ANYHIT && (cnt & RT_CNT_OCCLUDED)) {
         occluded = true;
         return true;
     }
-    cnt &= OCC_BIT - 1;
+    cnt &= RT_CNT_MASK;
     if (cnt > RT_LIST_K) return false;
     for (int k = 0; k < cnt; ++k) {
         const int i = list[k];
@@ -133,7 +132,7 @@ k_resolve_primary(ExactScene es, int W, int H, double tan_half, int y0, int y1,
         ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
         return;
     }
-    atomicAdd(&counters[1], c & (OCC_BIT - 1));
+    atomicAdd(&counters[1], c & RT_CNT_MASK);
     hit[p] = b.idx;
     if (b.idx != -1 && tuv) { tuv[3 * p] = b.t; tuv[3 * p + 1] = b.u; tuv[3 * p + 2] = b.v; }
 }
@@ -163,7 +162,7 @@ k_resolve_rays(ExactScene es, int n, const double* __restrict__ Sa, const double
         ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
         return;
     }
-    atomicAdd(&counters[1], (c & OCC_BIT) ? 0 : (c & (OCC_BIT - 1)));
+    atomicAdd(&counters[1], (c & RT_CNT_OCCLUDED) ? 0 : (c & RT_CNT_MASK));
     if (ANYHIT) {
         occ_out[p] = occ ? 1 : 0;
     } else {

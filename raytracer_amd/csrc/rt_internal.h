@@ -47,6 +47,11 @@ constexpr int RT_TILE_W = 16 * RT_RPL;   // pixel tile of one workgroup: 2x2 wav
 constexpr int RT_TILE_H = 16;
 constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
 
+// per-ray candidate counter written by the sweep: low bits = candidates pushed, plus
+constexpr int RT_CNT_OCCLUDED = 0x40000000;   // any-hit: a certain hit was found
+constexpr int RT_CNT_RETIRED = 0x20000000;    // unused ray slot (NaN origin, zero length, padding)
+constexpr int RT_CNT_MASK = 0x0FFFFFFF;
+
 // ---------------------------------------------------------------- device buffer helper
 // Grow-only device allocation; keeps steady-state frames free of hipMalloc/hipFree.
 struct DevBuf {
@@ -80,7 +85,7 @@ struct rt_scene {
 
     // per-call workspaces (grow-only)
     DevBuf ws_cnt, ws_list, ws_ovf, ws_counters;
-    DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_shcnt, ws_shlist;
+    DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1;
 };
 
 struct DevMaterial {
@@ -130,14 +135,19 @@ struct SweepArgs {
     // generic mode
     int n_rays;
     const double *S, *E;    // 3 doubles per ray
+    const int32_t* active;  // indexed mode: n_rays ray numbers to work on (else nullptr)
+    // triangle range of this launch, tile-aligned; resume = pick up cnt[] left by an earlier range
+    int tri_begin, tri_end;
+    int resume;
     // outputs
-    int32_t* cnt;           // per ray slot: number of candidates pushed (bit 31: certainly occluded)
-    int32_t* list;          // RT_LIST_K candidate triangle indices per ray slot
-    unsigned long long* tests;   // any-hit: pairs evaluated, accumulated per workgroup
+    int32_t* cnt;           // per ray: candidates pushed | RT_CNT_* flags
+    int32_t* list;          // RT_LIST_K candidate triangle indices per ray
+    unsigned long long* tests;   // pairs evaluated, accumulated per workgroup (may be nullptr)
 };
 int rt_launch_sweep_primary(const SweepArgs& a, hipStream_t st);
 int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st);
-int rt_primary_slots(int W, int y0, int y1);      // ray slots (tile-padded) of a band
+int rt_launch_compact(const int32_t* cnt, const int32_t* in, int n, int32_t* out, int* out_count,
+                      hipStream_t st);
 
 // rt_exact.hip
 struct ExactScene {

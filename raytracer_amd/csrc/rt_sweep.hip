@@ -2,17 +2,17 @@
 //
 // Replaces the per-ray launch of intersect_single_triangle_device
 // (triangle_intersection.cu:31-96,145-150: one thread per triangle, one launch per ray) by
-// the inverse mapping: every lane owns RT_RPL rays and sweeps ALL triangles, which arrive
+// the inverse mapping: every lane owns RT_RPL rays and sweeps the triangles, which arrive
 // as three float4 planes (v0|eu, e1|et, e2) staged through LDS in tiles of RT_TILE
 // triangles that all four waves of the workgroup read at wave-uniform addresses
 // (LDS broadcast, no bank conflicts).
 //
-// Arithmetic per (ray, triangle) pair: the full general-origin Moller-Trumbore evaluation
-// in fp32 FMA -- tvec = O - v0, pvec = D x e2, det = e1.pvec, U = tvec.pvec,
-// qvec = tvec x e1, V = D.qvec, T = e2.qvec -- which is the reference's Cramer solve
-// (:59-94) with D = E - S, u = U/det, v = V/det, t = T/det.  The three divisions are
-// replaced by sign-consistent products (a = U*det, b = V*det, c = det*det) so the hot loop
-// is 35 VALU instructions per pair and divides only for the rare pair that passes.
+// Arithmetic per (ray, triangle) pair: the general-origin Moller-Trumbore evaluation in fp32
+// FMA -- tvec = O - v0, pvec = D x e2, det = e1.pvec, U = tvec.pvec, qvec = tvec x e1,
+// V = D.qvec, T = e2.qvec -- which is the reference's Cramer solve (:59-94) with D = E - S,
+// u = U/det, v = V/det, t = T/det.  The three divisions are replaced by sign-consistent
+// products (a = U*det, b = V*det, c = det*det), so the hot loop is 32 VALU instructions per
+// pair; T and the division are evaluated only for the rare pair that passes.
 //
 // The fp32 pass is a conservative FILTER, not the final word: a pair passes when it lies
 // inside the triangle widened by a per-triangle rounding bound (eu, et; see rt_transform.hip).
@@ -21,39 +21,43 @@
 // arithmetic and comparison rules, so hit indices equal the fp64 result wherever the filter
 // bound holds.  A per-lane running minimum of t (updated only by pairs that are inside by
 // the same bound, i.e. certain hits) prunes candidates that cannot win.
+//
+// Any-hit (shadow) sweeps retire a ray at its first certain hit.  Because the workgroup only
+// stops when all of its rays have retired, long sweeps are cut into triangle ranges and the
+// surviving rays are compacted between ranges (k_compact), so the work per ray is
+// proportional to the index of its first occluder instead of the triangle count.
 #include "rt_internal.h"
 
 namespace {
 
 constexpr float RT_INF = __builtin_huge_valf();
-constexpr int OCC_BIT = 0x40000000;
 
 struct Ray {
     float ox, oy, oz;
     float dx, dy, dz;
     float best;      // smallest certain t so far (closest-hit mode)
     float best_hi;   // pruning threshold: best + its error bound; -inf = ray retired/invalid
-    int cnt;         // candidates pushed so far (OCC_BIT: certainly occluded, any-hit mode)
+    int cnt;         // candidates pushed so far, plus the RT_CNT_* flag bits
 };
 
 // One candidate that passed the widened barycentric test.  Rare: a few per ray per sweep.
 template <bool ANYHIT>
 __device__ __forceinline__ void rare_candidate(Ray& r, int32_t* __restrict__ list_slot, int tri,
-                                            float a, float b, float w, float d, float T,
-                                            float eu, float et)
+                                               float a, float b, float w, float d, float T,
+                                               float eu, float et)
 {
     const float rd = 1.0f / d;
     const float t = T * rd;
     const float terr = et * __builtin_fabsf(rd) + 2e-6f * __builtin_fabsf(t);
     if (!(t >= -terr) || !(t - terr <= r.best_hi)) return;
-    const int slot = r.cnt & (OCC_BIT - 1);
+    const int slot = r.cnt & RT_CNT_MASK;
     if (slot < RT_LIST_K) list_slot[slot] = tri;
     r.cnt++;
     const float margin = eu * __builtin_fabsf(d);
     const bool certain = (__builtin_fminf(__builtin_fminf(a, b), w) >= margin) && (t >= terr);
     if (certain) {
         if (ANYHIT) {
-            r.cnt |= OCC_BIT;
+            r.cnt |= RT_CNT_OCCLUDED;
             r.best_hi = -RT_INF;
         } else if (t < r.best) {
             r.best = t;
@@ -62,7 +66,7 @@ __device__ __forceinline__ void rare_candidate(Ray& r, int32_t* __restrict__ lis
     }
 }
 
-// The 35-instruction pair evaluation.  Returns true when the pair needs the rare path.
+// The pair evaluation.  Returns true when the pair needs the rare path.
 __device__ __forceinline__ bool pair_test(const Ray& r, const float4 V0, const float4 E1,
                                           const float4 E2, float& a, float& b, float& w,
                                           float& d, float& T)
@@ -96,12 +100,13 @@ __device__ __forceinline__ float opaque(float x)
     return x;
 }
 
-enum { MODE_PRIMARY = 0, MODE_RAYS_LINEAR = 1, MODE_RAYS_TILED = 2 };
+enum { MODE_PRIMARY = 0, MODE_RAYS_LINEAR = 1, MODE_RAYS_TILED = 2, MODE_RAYS_INDEXED = 3 };
 
 template <int MODE, bool ANYHIT>
 __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
 {
-    __shared__ float4 tile[2][3][RT_TILE];     // 24 KiB: double-buffered v0/e1/e2 planes
+    // double-buffered v0/e1/e2 planes of one tile
+    __shared__ float4 tile[2][3][RT_TILE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -109,6 +114,7 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
 
     Ray ray[RT_RPL];
     long slot[RT_RPL];        // index into cnt[] / list[] (band-local pixel or ray number)
+    bool in_range[RT_RPL];
 
     // ---- ray set-up ------------------------------------------------------------------
 #pragma unroll
@@ -119,6 +125,10 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
             const long j = (long)blockIdx.x * RT_RAYS_PER_WG + r * RT_WG + tid;
             valid = j < A.n_rays;
             slot[r] = j;
+        } else if (MODE == MODE_RAYS_INDEXED) {
+            const long j = (long)blockIdx.x * RT_RAYS_PER_WG + r * RT_WG + tid;
+            valid = j < A.n_rays;
+            slot[r] = valid ? (long)A.active[j] : 0;
         } else {
             // workgroup = RT_TILE_W x RT_TILE_H pixels; wave = (8*RPL) x 8; lane = 8 x 8
             const int tiles_x = (A.W + RT_TILE_W - 1) / RT_TILE_W;
@@ -135,6 +145,7 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
                 Ez = A.ez;
             }
         }
+        in_range[r] = valid;
         if (MODE != MODE_PRIMARY && valid) {
             const double* s = A.S + 3 * slot[r];
             const double* e = A.E + 3 * slot[r];
@@ -146,44 +157,55 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
         // candidates is unchanged and the per-triangle error bounds need no |D| factor.
         const double Dx = Ex - Sx, Dy = Ey - Sy, Dz = Ez - Sz;
         const double inv = 1.0 / __builtin_sqrt(Dx * Dx + Dy * Dy + Dz * Dz);
-        ray[r].ox = opaque((float)Sx);
-        ray[r].oy = opaque((float)Sy);
-        ray[r].oz = opaque((float)Sz);
-        ray[r].dx = (float)(Dx * inv);
-        ray[r].dy = (float)(Dy * inv);
-        ray[r].dz = (float)(Dz * inv);
         if (!(inv == inv) || inv > 1e300) valid = false;      // zero-length ray hits nothing
-        if (!valid) { ray[r].dx = ray[r].dy = ray[r].dz = 0.0f; ray[r].ox = ray[r].oy = ray[r].oz = 0.0f; }
+        ray[r].ox = opaque(valid ? (float)Sx : 0.0f);
+        ray[r].oy = opaque(valid ? (float)Sy : 0.0f);
+        ray[r].oz = opaque(valid ? (float)Sz : 0.0f);
+        ray[r].dx = valid ? (float)(Dx * inv) : 0.0f;
+        ray[r].dy = valid ? (float)(Dy * inv) : 0.0f;
+        ray[r].dz = valid ? (float)(Dz * inv) : 0.0f;
         ray[r].best = RT_INF;
         ray[r].best_hi = valid ? RT_INF : -RT_INF;
-        ray[r].cnt = 0;
+        ray[r].cnt = valid ? 0 : RT_CNT_RETIRED;
+        if (A.resume && in_range[r]) {
+            // a later triangle range of the same sweep: pick up the candidate count
+            ray[r].cnt = A.cnt[slot[r]];
+            if (ray[r].cnt & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) ray[r].best_hi = -RT_INF;
+        }
     }
 
     // ---- tile loop -------------------------------------------------------------------
-    const int ntiles = A.num_tris_padded / RT_TILE;
+    const int t_begin = A.tri_begin / RT_TILE, t_end = A.tri_end / RT_TILE;
     auto stage = [&](int t, int buf) {
-        // 3 planes x RT_TILE float4 = 12 KiB; each wave moves 64 float4 (1 KiB) per plane with
-        // one LDS-DMA instruction: global source per lane, LDS destination wave base + 16*lane.
-        const long g = (long)t * RT_TILE + tid;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(A.v0 + g),
-            (__attribute__((address_space(3))) void*)&tile[buf][0][wave * 64], 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(A.e1 + g),
-            (__attribute__((address_space(3))) void*)&tile[buf][1][wave * 64], 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(A.e2 + g),
-            (__attribute__((address_space(3))) void*)&tile[buf][2][wave * 64], 16, 0, 0);
+        // 3 planes x RT_TILE float4; one LDS-DMA instruction moves 64 float4 (1 KiB) per wave:
+        // global source per lane, LDS destination = wave-uniform base + 16 * lane.
+#pragma unroll
+        for (int c = 0; c < (RT_TILE / 64 + 3) / 4; ++c) {
+            const int chunk = c * 4 + wave;
+            if (chunk < RT_TILE / 64) {
+                const long g = (long)t * RT_TILE + chunk * 64 + lane;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(A.v0 + g),
+                    (__attribute__((address_space(3))) void*)&tile[buf][0][chunk * 64], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(A.e1 + g),
+                    (__attribute__((address_space(3))) void*)&tile[buf][1][chunk * 64], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(A.e2 + g),
+                    (__attribute__((address_space(3))) void*)&tile[buf][2][chunk * 64], 16, 0, 0);
+            }
+        }
     };
 
-    stage(0, 0);
-    __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0) & lgkmcnt(0)
-    __syncthreads();
-
     unsigned long long tiles_done = 0;
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+    if (t_begin < t_end) {
+        stage(t_begin, 0);
+        __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0) & lgkmcnt(0)
+        __syncthreads();
+    }
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        if (t + 1 < t_end) stage(t + 1, buf ^ 1);
         const float4* __restrict__ pv0 = tile[buf][0];
         const float4* __restrict__ pe1 = tile[buf][1];
         const float4* __restrict__ pe2 = tile[buf][2];
@@ -216,20 +238,31 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
 
     // ---- results ---------------------------------------------------------------------
 #pragma unroll
-    for (int r = 0; r < RT_RPL; ++r) {
-        bool in_range;
-        if (MODE == MODE_RAYS_LINEAR) in_range = slot[r] < A.n_rays;
-        else {
-            const int tiles_x = (A.W + RT_TILE_W - 1) / RT_TILE_W;
-            const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-            const int px = txi * RT_TILE_W + (wave & 1) * (8 * RT_RPL) + r * 8 + (lane & 7);
-            const int py = A.y0 + tyi * RT_TILE_H + (wave >> 1) * 8 + (lane >> 3);
-            in_range = (px < A.W) && (py < A.y1);
-        }
-        if (in_range) A.cnt[slot[r]] = ray[r].cnt;
-    }
+    for (int r = 0; r < RT_RPL; ++r)
+        if (in_range[r]) A.cnt[slot[r]] = ray[r].cnt;
     if (A.tests && tid == 0)
         atomicAdd(A.tests, tiles_done * (unsigned long long)RT_TILE * RT_RAYS_PER_WG);
+}
+
+// Survivors of an any-hit range: rays that are neither certainly occluded nor unused.
+// `in` == nullptr means "all rays 0..n-1".  Each wave reserves one contiguous block of the
+// output, so rays that shared a wave stay together.
+__global__ void __launch_bounds__(RT_WG)
+k_compact(const int32_t* __restrict__ cnt, const int32_t* __restrict__ in, int n,
+          int32_t* __restrict__ out, int* __restrict__ out_count)
+{
+    const long j = (long)blockIdx.x * RT_WG + threadIdx.x;
+    int id = -1;
+    if (j < n) {
+        id = in ? in[j] : (int)j;
+        if (cnt[id] & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) id = -1;
+    }
+    const unsigned long long m = __ballot(id >= 0);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(out_count, __popcll(m));
+    base = __shfl(base, 0);
+    if (id >= 0) out[base + __popcll(m & ((1ull << lane) - 1))] = id;
 }
 
 template <int MODE, bool ANYHIT>
@@ -246,8 +279,6 @@ int launch(const SweepArgs& a, dim3 grid, hipStream_t st)
 
 }  // namespace
 
-int rt_primary_slots(int W, int y0, int y1) { return W * (y1 - y0); }
-
 static int check_common(const SweepArgs& a)
 {
     if (!a.v0 || !a.e1 || !a.e2 || !a.cnt || !a.list) {
@@ -257,6 +288,12 @@ static int check_common(const SweepArgs& a)
     if (a.num_tris_padded <= 0 || a.num_tris_padded % RT_TILE != 0 ||
         a.num_tris > a.num_tris_padded) {
         rt_set_error("sweep: triangle planes must be padded to a multiple of %d", RT_TILE);
+        return RT_E_ARG;
+    }
+    if (a.tri_begin < 0 || a.tri_end > a.num_tris_padded || a.tri_begin > a.tri_end ||
+        a.tri_begin % RT_TILE != 0 || a.tri_end % RT_TILE != 0) {
+        rt_set_error("sweep: triangle range [%d,%d) must be tile-aligned inside [0,%d]",
+                     a.tri_begin, a.tri_end, a.num_tris_padded);
         return RT_E_ARG;
     }
     return RT_OK;
@@ -283,6 +320,12 @@ int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st)
         rt_set_error("sweep: null ray arrays");
         return RT_E_ARG;
     }
+    if (a.n_rays <= 0) return RT_OK;
+    if (a.active) {     // indexed: n_rays entries of `active` name the rays
+        dim3 grid((a.n_rays + RT_RAYS_PER_WG - 1) / RT_RAYS_PER_WG, 1);
+        return anyhit ? launch<MODE_RAYS_INDEXED, true>(a, grid, st)
+                      : launch<MODE_RAYS_INDEXED, false>(a, grid, st);
+    }
     if (a.W > 0) {      // tiled: n_rays = layers * W * (y1-y0)
         const long npix = (long)a.W * (a.y1 - a.y0);
         if (npix <= 0 || a.n_rays % npix != 0) {
@@ -296,8 +339,21 @@ int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st)
         return anyhit ? launch<MODE_RAYS_TILED, true>(a, grid, st)
                       : launch<MODE_RAYS_TILED, false>(a, grid, st);
     }
-    if (a.n_rays <= 0) return RT_OK;
     dim3 grid((a.n_rays + RT_RAYS_PER_WG - 1) / RT_RAYS_PER_WG, 1);
     return anyhit ? launch<MODE_RAYS_LINEAR, true>(a, grid, st)
                   : launch<MODE_RAYS_LINEAR, false>(a, grid, st);
+}
+
+int rt_launch_compact(const int32_t* cnt, const int32_t* in, int n, int32_t* out, int* out_count,
+                      hipStream_t st)
+{
+    if (n <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_compact, dim3((n + RT_WG - 1) / RT_WG), dim3(RT_WG), 0, st, cnt, in, n, out,
+                       out_count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        rt_set_error("compact launch failed: %s", hipGetErrorString(e));
+        return RT_E_HIP;
+    }
+    return RT_OK;
 }
