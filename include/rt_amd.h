@@ -170,6 +170,10 @@ typedef struct rt_profile {
     uint64_t exact_overflow;    /* rays that fell back to the full fp64 sweep */
     uint64_t rays_live;         /* generic-ray launches: rays in use (unused slots excluded) */
 } rt_profile;
+/* Compile-time shape of the sweep kernel: formulation (0 = textbook Moller-Trumbore order,
+ * 1 = shared cross product + stored normal), triangles per LDS tile, rays per lane, and the
+ * fp32 flops the hot loop executes per ray-triangle pair (FMA = 2). */
+int rt_sweep_config(int* form, int* tile_tris, int* rays_per_lane, int* flop_per_pair);
 int rt_profile_enable(int on);     /* wraps sweep launches in HIP events and reads the device
                                       counters back (adds a sync per launch); the ray and
                                       candidate counts above are only collected while on */

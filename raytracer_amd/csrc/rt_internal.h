@@ -35,11 +35,21 @@ void rt_set_error(const char* fmt, ...);
 // ---------------------------------------------------------------- tunables
 constexpr int RT_WG = 256;          // threads per workgroup of every kernel here (4 waves)
 #ifndef RT_TILE_TRIS
-#define RT_TILE_TRIS 256
+#define RT_TILE_TRIS 128
 #endif
 #ifndef RT_RAYS_PER_LANE
 #define RT_RAYS_PER_LANE 2
 #endif
+#ifndef RT_SWEEP_FORM
+#define RT_SWEEP_FORM 1     // 0 = textbook Moller-Trumbore order, 1 = shared cross product + stored normal
+#endif
+#ifndef RT_PREFETCH
+#define RT_PREFETCH 1       // issue the next triangle's LDS reads before the current arithmetic
+#endif
+#ifndef RT_MERGED_BRANCH
+#define RT_MERGED_BRANCH 0  // 1 = one rare-path branch per triangle (all rays of the lane) instead of per pair
+#endif
+constexpr int RT_PLANES = RT_SWEEP_FORM == 1 ? 4 : 3;   // float4 planes staged per tile
 constexpr int RT_TILE = RT_TILE_TRIS;      // triangles per LDS tile of the sweep
 constexpr int RT_RPL = RT_RAYS_PER_LANE;   // rays per lane in the sweep
 constexpr int RT_LIST_K = 16;       // candidate slots per ray handed to the fp64 confirmation
@@ -79,8 +89,8 @@ struct rt_scene {
     bool has_tex_idx = false;
 
     // fp32 sweep buffer: three float4 planes of num_tris_padded entries
-    //   v0 = (A.x, A.y, A.z, eu)   e1 = (B-A, et)   e2 = (C-A, 0)
-    DevBuf pv0, pe1, pe2;
+    //   v0 = (A.x, A.y, A.z, eu)   e1 = (B-A, et)   e2 = (C-A, 0)   nn = (e2 x e1, 0)
+    DevBuf pv0, pe1, pe2, pnn;
     DevBuf scratch_max;         // 1 float: max |coordinate| of the eye-space vertices
 
     // per-call workspaces (grow-only)
@@ -127,7 +137,7 @@ int rt_launch_pack(rt_scene* sc, hipStream_t st);
 
 // rt_sweep.hip
 struct SweepArgs {
-    const float4 *v0, *e1, *e2;
+    const float4 *v0, *e1, *e2, *nn;   // nn = e2 x e1 (only read when RT_SWEEP_FORM == 1)
     int num_tris, num_tris_padded;
     // primary mode
     int W, H, y0, y1;

@@ -3,7 +3,7 @@
 // Replaces the per-ray launch of intersect_single_triangle_device
 // (triangle_intersection.cu:31-96,145-150: one thread per triangle, one launch per ray) by
 // the inverse mapping: every lane owns RT_RPL rays and sweeps the triangles, which arrive
-// as three float4 planes (v0|eu, e1|et, e2) staged through LDS in tiles of RT_TILE
+// as float4 planes (v0|eu, e1|et, e2, nn) staged through LDS in tiles of RT_TILE
 // triangles that all four waves of the workgroup read at wave-uniform addresses
 // (LDS broadcast, no bank conflicts).
 //
@@ -67,27 +67,49 @@ __device__ __forceinline__ void rare_candidate(Ray& r, int32_t* __restrict__ lis
 }
 
 // The pair evaluation.  Returns true when the pair needs the rare path.
+//
+// Both forms compute the same three scalar triple products
+//     det = e1.(D x e2),  U = tvec.(D x e2),  V = D.(tvec x e1)        (tvec = O - v0)
+// and defer the fourth, T = e2.(tvec x e1), to the rare path.
+//   RT_SWEEP_FORM 0: the textbook Moller-Trumbore order (pvec = D x e2, qvec = tvec x e1):
+//                    24 instructions for det, U, V.
+//   RT_SWEEP_FORM 1: one shared cross product c = tvec x D, U = e2.c, V = -e1.c, and
+//                    det = D.nn with the per-triangle nn = e2 x e1 precomputed by k_pack:
+//                    18 instructions.  T = -tvec.nn.
+// The acceptance test is division-free: with a = U*det, b = V*det, w = det*det - a - b the
+// pair passes when min(a, b, w) + eu*|det| > 0.
 __device__ __forceinline__ bool pair_test(const Ray& r, const float4 V0, const float4 E1,
-                                          const float4 E2, float& a, float& b, float& w,
-                                          float& d, float& T)
+                                          const float4 E2, const float4 NN, float& a, float& b,
+                                          float& w, float& d, float& T)
 {
     const float tx = r.ox - V0.x, ty = r.oy - V0.y, tz = r.oz - V0.z;
-    // pvec = D x e2
+#if RT_SWEEP_FORM == 0
     const float px = __builtin_fmaf(r.dy, E2.z, -(r.dz * E2.y));
     const float py = __builtin_fmaf(r.dz, E2.x, -(r.dx * E2.z));
     const float pz = __builtin_fmaf(r.dx, E2.y, -(r.dy * E2.x));
     d = __builtin_fmaf(E1.z, pz, __builtin_fmaf(E1.y, py, E1.x * px));
     const float U = __builtin_fmaf(tz, pz, __builtin_fmaf(ty, py, tx * px));
-    // qvec = tvec x e1
     const float qx = __builtin_fmaf(ty, E1.z, -(tz * E1.y));
     const float qy = __builtin_fmaf(tz, E1.x, -(tx * E1.z));
     const float qz = __builtin_fmaf(tx, E1.y, -(ty * E1.x));
     const float V = __builtin_fmaf(r.dz, qz, __builtin_fmaf(r.dy, qy, r.dx * qx));
     T = __builtin_fmaf(E2.z, qz, __builtin_fmaf(E2.y, qy, E2.x * qx));
-    const float c = d * d;
+    (void)NN;
     a = U * d;
     b = V * d;
-    w = (c - a) - b;
+#else
+    // c = tvec x D
+    const float cx = __builtin_fmaf(ty, r.dz, -(tz * r.dy));
+    const float cy = __builtin_fmaf(tz, r.dx, -(tx * r.dz));
+    const float cz = __builtin_fmaf(tx, r.dy, -(ty * r.dx));
+    d = __builtin_fmaf(r.dz, NN.z, __builtin_fmaf(r.dy, NN.y, r.dx * NN.x));
+    const float U = __builtin_fmaf(E2.z, cz, __builtin_fmaf(E2.y, cy, E2.x * cx));
+    const float Vn = __builtin_fmaf(E1.z, cz, __builtin_fmaf(E1.y, cy, E1.x * cx));   // = -V
+    T = -__builtin_fmaf(tz, NN.z, __builtin_fmaf(ty, NN.y, tx * NN.x));
+    a = U * d;
+    b = -(Vn * d);
+#endif
+    w = __builtin_fmaf(d, d, -a) - b;
     const float m = __builtin_fminf(__builtin_fminf(a, b), w);      // v_min3_f32
     return __builtin_fmaf(V0.w, __builtin_fabsf(d), m) > 0.0f;
 }
@@ -106,7 +128,7 @@ template <int MODE, bool ANYHIT>
 __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
 {
     // double-buffered v0/e1/e2 planes of one tile
-    __shared__ float4 tile[2][3][RT_TILE];
+    __shared__ float4 tile[2][RT_PLANES][RT_TILE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -193,6 +215,11 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void*)(A.e2 + g),
                     (__attribute__((address_space(3))) void*)&tile[buf][2][chunk * 64], 16, 0, 0);
+#if RT_SWEEP_FORM == 1
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(A.nn + g),
+                    (__attribute__((address_space(3))) void*)&tile[buf][3][chunk * 64], 16, 0, 0);
+#endif
             }
         }
     };
@@ -209,19 +236,51 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
         const float4* __restrict__ pv0 = tile[buf][0];
         const float4* __restrict__ pe1 = tile[buf][1];
         const float4* __restrict__ pe2 = tile[buf][2];
+        const float4* __restrict__ pnn = tile[buf][RT_PLANES - 1];
         const int tri0 = t * RT_TILE;
+        // The rare path splits the loop body into basic blocks, which stops the compiler from
+        // hoisting the next triangle's LDS reads above the current triangle's arithmetic; the
+        // reads are therefore issued one triangle ahead by hand (RT_PREFETCH).
+#if RT_PREFETCH
+        float4 nV0 = pv0[0], nE1 = pe1[0], nE2 = pe2[0], nNN = pnn[0];
+#endif
 #pragma unroll 2
         for (int j = 0; j < RT_TILE; ++j) {
+#if RT_PREFETCH
+            const float4 V0 = nV0, E1 = nE1, E2 = nE2, NN = nNN;
+            const int jn = (j + 1) & (RT_TILE - 1);     // last iteration re-reads entry 0 (unused)
+            nV0 = pv0[jn]; nE1 = pe1[jn]; nE2 = pe2[jn]; nNN = pnn[jn];
+#else
             const float4 V0 = pv0[j];
             const float4 E1 = pe1[j];
             const float4 E2 = pe2[j];
+            const float4 NN = pnn[j];       // form 0: aliases the e2 plane and is unused
+#endif
+#if RT_MERGED_BRANCH
+            // one exec-mask branch per triangle instead of one per pair
+            float a[RT_RPL], b[RT_RPL], w[RT_RPL], d[RT_RPL], T[RT_RPL];
+            bool pass[RT_RPL], any = false;
+#pragma unroll
+            for (int r = 0; r < RT_RPL; ++r) {
+                pass[r] = pair_test(ray[r], V0, E1, E2, NN, a[r], b[r], w[r], d[r], T[r]);
+                any = any || pass[r];
+            }
+            if (__builtin_expect(any, 0)) {
+#pragma unroll
+                for (int r = 0; r < RT_RPL; ++r)
+                    if (pass[r])
+                        rare_candidate<ANYHIT>(ray[r], A.list + slot[r] * RT_LIST_K, tri0 + j,
+                                               a[r], b[r], w[r], d[r], T[r], V0.w, E1.w);
+            }
+#else
 #pragma unroll
             for (int r = 0; r < RT_RPL; ++r) {
                 float a, b, w, d, T;
-                if (__builtin_expect(pair_test(ray[r], V0, E1, E2, a, b, w, d, T), 0))
+                if (__builtin_expect(pair_test(ray[r], V0, E1, E2, NN, a, b, w, d, T), 0))
                     rare_candidate<ANYHIT>(ray[r], A.list + slot[r] * RT_LIST_K, tri0 + j,
                                            a, b, w, d, T, V0.w, E1.w);
             }
+#endif
         }
         ++tiles_done;
         __builtin_amdgcn_s_waitcnt(0);
@@ -281,7 +340,7 @@ int launch(const SweepArgs& a, dim3 grid, hipStream_t st)
 
 static int check_common(const SweepArgs& a)
 {
-    if (!a.v0 || !a.e1 || !a.e2 || !a.cnt || !a.list) {
+    if (!a.v0 || !a.e1 || !a.e2 || !a.nn || !a.cnt || !a.list) {
         rt_set_error("sweep: null buffer");
         return RT_E_ARG;
     }

@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(RT_WG)
 k_pack(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
        const int* __restrict__ iA, const int* __restrict__ iB, const int* __restrict__ iC,
        int num_tris, int num_tris_padded, const unsigned* __restrict__ max_bits,
-       float4* __restrict__ v0, float4* __restrict__ e1, float4* __restrict__ e2)
+       float4* __restrict__ v0, float4* __restrict__ e1, float4* __restrict__ e2,
+       float4* __restrict__ nn)
 {
     const int i = blockIdx.x * RT_WG + threadIdx.x;
     if (i >= num_tris_padded) return;
@@ -52,6 +53,7 @@ k_pack(const double* __restrict__ x, const double* __restrict__ y, const double*
         v0[i] = make_float4(0, 0, 0, 0);
         e1[i] = make_float4(0, 0, 0, 0);
         e2[i] = make_float4(0, 0, 0, 0);
+        nn[i] = make_float4(0, 0, 0, 0);
         return;
     }
     const int a = iA[i], b = iB[i], c = iC[i];
@@ -66,6 +68,9 @@ k_pack(const double* __restrict__ x, const double* __restrict__ y, const double*
     v0[i] = make_float4((float)ax, (float)ay, (float)az, (float)eu);
     e1[i] = make_float4((float)e1x, (float)e1y, (float)e1z, (float)et);
     e2[i] = make_float4((float)e2x, (float)e2y, (float)e2z, 0.0f);
+    // nn = e2 x e1, so that det = e1.(D x e2) = D.nn
+    nn[i] = make_float4((float)(e2y * e1z - e2z * e1y), (float)(e2z * e1x - e2x * e1z),
+                        (float)(e2x * e1y - e2y * e1x), 0.0f);
 }
 
 }  // namespace
@@ -91,7 +96,7 @@ int rt_launch_pack(rt_scene* sc, hipStream_t st)
                        sc->ex.as<double>(), sc->ey.as<double>(), sc->ez.as<double>(),
                        sc->iA.as<int>(), sc->iB.as<int>(), sc->iC.as<int>(), sc->num_tris, np,
                        sc->scratch_max.as<unsigned>(), sc->pv0.as<float4>(), sc->pe1.as<float4>(),
-                       sc->pe2.as<float4>());
+                       sc->pe2.as<float4>(), sc->pnn.as<float4>());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("pack launch failed: %s", hipGetErrorString(e));
