@@ -36,6 +36,8 @@ WORKLOADS = {
     "bunny_class_4k": ("sphere", 69_451, 3840, 2160),
     "teapot_class_480p": ("torus", 6_320, 640, 480),
     "soup100k_1080p": ("soup", 100_000, 1920, 1080),
+    # config 5: 360-frame orbit, one M3d transform per frame (step k renders frame k)
+    "teapot_seq_4k": ("torus", 6_320, 3840, 2160),
 }
 
 
@@ -52,7 +54,7 @@ def cpu_baseline(mesh, frame, W, H, budget_s: float = 15.0):
     """CPU oracle (strict fp64 restatement of the reference's formulas, OpenMP over rows) on
     a bounded row sample of the same frame; primary rays only."""
     from oracle import oracle as O
-    from raytracer_amd import kernel
+    from raytracer_amd import kernel, parallel
     X, Y, Z = O.transform(mesh, kernel.frame_matrix(frame, "obmat"))
     osc = O.Scene(mesh, X, Y, Z)
     ofr = O.frame_from(frame)
@@ -89,6 +91,8 @@ def main() -> None:
     ap.add_argument("--workload", default="soup1m_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the gather even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -108,14 +112,19 @@ def main() -> None:
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     kind, tris, W, H = WORKLOADS[args.workload]
     mesh = make_mesh(kind, tris)
-    frame = kernel.driver_frame(0)
-    obmat = kernel.frame_matrix(frame, "obmat")
+    sequence = args.workload.endswith("_seq_4k")
+    frames = [kernel.driver_frame(k, 360) for k in range(360)] if sequence else [kernel.driver_frame(0)]
+    obmats = [kernel.frame_matrix(f, "obmat") for f in frames]
+    frame = frames[0]
+    step_no = [0]
     sc = kernel.Scene(mesh, device=local_rank)
     y0, y1 = kernel.band(H, world, rank)
     rows = y1 - y0
@@ -124,15 +133,20 @@ def main() -> None:
     out = {"hit": torch.empty((rows, W), dtype=torch.int32, device=dev),
            "rgb8": torch.zeros((max_rows, W, 3), dtype=torch.uint8, device=dev)}
     gathered = ([torch.empty((max_rows, W, 3), dtype=torch.uint8, device=dev) for _ in range(world)]
-                if (world > 1 and rank == 0) else None)
+                if (use_dist and rank == 0) else None)
     screen = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
 
     def step():
-        sc.transform(obmat)                       # driver.c:110 on the device-resident mesh
-        sc.render_rows(frame, W, H, TAN_HALF, y0, y1, want=("hit", "rgb8"),
+        k = step_no[0] % len(frames)
+        step_no[0] += 1
+        sc.transform(obmats[k])                   # driver.c:110 on the device-resident mesh
+        sc.render_rows(frames[k], W, H, TAN_HALF, y0, y1, want=("hit", "rgb8"),
                        out={"hit": out["hit"], "rgb8": out["rgb8"][:rows]})
-        if world > 1:
-            dist.gather(out["rgb8"], gathered, dst=0)        # RCCL over xGMI
+        if use_dist:
+            if world > 1:
+                parallel.gather_bands(out["rgb8"], H, world, rank, dst=0, out=gathered)   # RCCL over xGMI
+            else:
+                dist.gather(out["rgb8"], gathered, dst=0)
             if rank == 0:
                 for r in range(world):
                     a, b = kernel.band(H, world, r)
@@ -141,7 +155,7 @@ def main() -> None:
             sc.place_rows(out["rgb8"][:rows], W, H, y0, y1, screen)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -164,7 +178,7 @@ def main() -> None:
                          dtype=torch.float64, device=dev)
     tmax = stats.clone()
     tsum = stats.clone()
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
     if rank == 0:
@@ -197,6 +211,7 @@ def main() -> None:
             "config": {"workload": args.workload, "mesh": mesh.name, "triangles": mesh.num_tris,
                        "width": W, "height": H, "lights": frame.num_lights,
                        "sharding": f"{world} row band(s), RCCL gather to rank 0" if world > 1 else "single GPU"},
+            "frames_per_s": steps / wall,
             "primary_mrays_per_s": rays_p / (wall / steps) / 1e6,
             "rays_per_frame": {"primary": rays_p, "shadow": rays_s},
             "tests_per_s": tests / (wall / steps),
@@ -220,7 +235,7 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(mesh, frame, W, H, args.cpu_budget)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -147,7 +147,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
     DevBuf* bufs[] = {&sc->ox, &sc->oy, &sc->oz, &sc->ex, &sc->ey, &sc->ez, &sc->nx, &sc->ny, &sc->nz,
                       &sc->tu, &sc->tv, &sc->iA, &sc->iB, &sc->iC, &sc->iAn, &sc->iBn, &sc->iCn,
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->pv0,
-                      &sc->pe1, &sc->pe2, &sc->pnn, &sc->scratch_max, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf,
+                      &sc->pe1, &sc->pe2, &sc->pnn, &sc->scratch_max, &sc->mat_dev, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
                       &sc->ws_occ, &sc->ws_act0, &sc->ws_act1};
     for (DevBuf* b : bufs) b->release();
@@ -370,7 +370,7 @@ static int transform_into(rt_scene* sc, const double m[4][4], bool bake)
         return RT_E_STATE;
     }
     hipStream_t st = rt_g().stream;
-    DevBuf mdev;    // 128 B; tiny and rare enough for a temporary
+    DevBuf& mdev = sc->mat_dev;     // kept with the scene: no allocation per frame
     RT_TRY(mdev.reserve(16 * sizeof(double)));
     int rc = RT_OK;
     do {
@@ -405,7 +405,6 @@ static int transform_into(rt_scene* sc, const double m[4][4], bool bake)
             rc = RT_E_HIP;
         }
     } while (0);
-    mdev.release();
     return rc;
 }
 

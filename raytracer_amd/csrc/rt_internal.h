@@ -92,6 +92,7 @@ struct rt_scene {
     //   v0 = (A.x, A.y, A.z, eu)   e1 = (B-A, et)   e2 = (C-A, 0)   nn = (e2 x e1, 0)
     DevBuf pv0, pe1, pe2, pnn;
     DevBuf scratch_max;         // 1 float: max |coordinate| of the eye-space vertices
+    DevBuf mat_dev;             // the 4x4 of the current transform
 
     // per-call workspaces (grow-only)
     DevBuf ws_cnt, ws_list, ws_ovf, ws_counters;
