@@ -190,13 +190,13 @@ def main() -> None:
         # roofline of the dominant kernel: rank 0's closest-hit sweep launches
         sweep_ms_avg = prof.sweep_ms / max(prof.sweep_launches, 1)
         tests_per_launch = prof.sweep_tests / max(prof.sweep_launches, 1)
-        achieved = F_TEST * tests_per_launch / (sweep_ms_avg * 1e-3) / 1e12 if sweep_ms_avg > 0 else 0.0
+        nominal = F_TEST * tests_per_launch / (sweep_ms_avg * 1e-3) / 1e12 if sweep_ms_avg > 0 else 0.0
         import ctypes as C
         from raytracer_amd import _lib
         cfg = [C.c_int() for _ in range(4)]
         _lib.load().rt_sweep_config(*[C.byref(c) for c in cfg])
         f_exec = float(cfg[3].value)
-        achieved_exec = achieved * f_exec / F_TEST
+        achieved = nominal * f_exec / F_TEST      # flops the hot loop really executes
         res = {
             "metric": "Mrays/s and ray-tri tests/s (% fp32 peak) at 1/2/4/8 MI355X vs host-CPU ref",
             "value": (rays_p + rays_s) / (wall / steps) / 1e6,
@@ -219,16 +219,19 @@ def main() -> None:
             "hit_fraction_rank0": hit_frac,
             "fp64_confirmations_per_frame": tsum[8].item() / steps,
             "overflow_rays_per_frame": tsum[9].item() / steps,
+            # Roofline of the dominant kernel.  `achieved` prices a ray-triangle pair at the fp32
+            # flops the hot loop executes for it (rocprof SQ_INSTS_VALU_{ADD,MUL,FMA}_F32, see
+            # profiles/), because the kernel evaluates the test lazily; the nominal 46 flop of a
+            # full Moller-Trumbore test with its divisions is given beside it, not instead of it.
             "roofline": {
                 "bound": "valu-fp32", "kernel": "k_sweep<primary,closest>",
                 "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS,
                 "avg_launch_ms": sweep_ms_avg, "tests_per_launch": tests_per_launch,
-                "flop_per_test": F_TEST, "traffic": None,
-                # conservative cross-check: flops the hot loop really executes per pair
-                # (rocprof SQ_INSTS_VALU_{ADD,MUL,FMA}_F32, see profiles/), same duration
-                "flop_per_test_executed": f_exec, "achieved_executed": achieved_exec,
-                "frac_executed": achieved_exec / PEAK_FP32_TFLOPS,
+                "tests_per_s": tests_per_launch / (sweep_ms_avg * 1e-3) if sweep_ms_avg > 0 else 0.0,
+                "flop_per_test": f_exec, "traffic": None,
+                "flop_per_test_nominal": F_TEST, "achieved_nominal": nominal,
+                "frac_nominal": nominal / PEAK_FP32_TFLOPS,
                 "sweep_kernel": {"form": cfg[0].value, "tile_tris": cfg[1].value, "rays_per_lane": cfg[2].value},
             },
         }

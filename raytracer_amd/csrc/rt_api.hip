@@ -86,8 +86,10 @@ extern "C" int rt_sweep_config(int* form, int* tile_tris, int* rays_per_lane, in
     if (form) *form = RT_SWEEP_FORM;
     if (tile_tris) *tile_tris = RT_TILE;
     if (rays_per_lane) *rays_per_lane = RT_RPL;
-    // form 0: 5 add + 12 mul + 12 fma = 41; form 1: 4 add + 8 mul + 11 fma = 34 (T deferred in both)
-    if (flop_per_pair) *flop_per_pair = RT_SWEEP_FORM == 1 ? 34 : 41;
+    // hot-loop flops per pair (FMA = 2), before the lazily evaluated parts:
+    //   form 0: 5 add + 12 mul + 12 fma = 41
+    //   form 1: 4 add + 8 mul + 11 fma = 34;  staged (u test first): 3 add + 6 mul + 9 fma = 27
+    if (flop_per_pair) *flop_per_pair = RT_SWEEP_FORM == 1 ? (RT_STAGED ? 27 : 34) : 41;
     return RT_OK;
 }
 

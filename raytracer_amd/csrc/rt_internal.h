@@ -46,8 +46,8 @@ constexpr int RT_WG = 256;          // threads per workgroup of every kernel her
 #ifndef RT_PREFETCH
 #define RT_PREFETCH 1       // issue the next triangle's LDS reads before the current arithmetic
 #endif
-#ifndef RT_MERGED_BRANCH
-#define RT_MERGED_BRANCH 0  // 1 = one rare-path branch per triangle (all rays of the lane) instead of per pair
+#ifndef RT_STAGED
+#define RT_STAGED (RT_SWEEP_FORM == 1)   // lazy evaluation: u test first, V / v / u+v / T only inside the u slab
 #endif
 constexpr int RT_PLANES = RT_SWEEP_FORM == 1 ? 4 : 3;   // float4 planes staged per tile
 constexpr int RT_TILE = RT_TILE_TRIS;      // triangles per LDS tile of the sweep

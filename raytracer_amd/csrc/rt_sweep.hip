@@ -78,7 +78,7 @@ __device__ __forceinline__ void rare_candidate(Ray& r, int32_t* __restrict__ lis
 //                    18 instructions.  T = -tvec.nn.
 // The acceptance test is division-free: with a = U*det, b = V*det, w = det*det - a - b the
 // pair passes when min(a, b, w) + eu*|det| > 0.
-__device__ __forceinline__ bool pair_test(const Ray& r, const float4 V0, const float4 E1,
+[[maybe_unused]] __device__ __forceinline__ bool pair_test(const Ray& r, const float4 V0, const float4 E1,
                                           const float4 E2, const float4 NN, float& a, float& b,
                                           float& w, float& d, float& T)
 {
@@ -112,6 +112,40 @@ __device__ __forceinline__ bool pair_test(const Ray& r, const float4 V0, const f
     w = __builtin_fmaf(d, d, -a) - b;
     const float m = __builtin_fminf(__builtin_fminf(a, b), w);      // v_min3_f32
     return __builtin_fmaf(V0.w, __builtin_fabsf(d), m) > 0.0f;
+}
+
+// RT_SWEEP_FORM 1 with lazy evaluation, the SIMD counterpart of the early returns in
+// intersect_single_triangle_device (triangle_intersection.cu:67-94): the u test needs only
+// tvec, c = tvec x D, det = D.nn and U = e2.c (20 instructions with its compare).  V = -e1.c,
+// the v and u+v tests and finally T are evaluated only where some lane of the wave is inside the
+// u slab, which for coherent rays and small triangles is a few percent of the wave-pairs.
+// Tolerances: the u slab is widened by e2.w = 2*eu because u <= 1 is implied by the final
+// w >= -eu*|det| and b >= -eu*|det| only up to 2*eu*|det|.
+template <bool ANYHIT>
+__device__ __forceinline__ void staged_pair(Ray& r, int32_t* __restrict__ list_slot, int tri,
+                                            const float4 V0, const float4 E2, const float4 NN,
+                                            const float4* __restrict__ pe1_j)
+{
+    const float tx = r.ox - V0.x, ty = r.oy - V0.y, tz = r.oz - V0.z;
+    const float cx = __builtin_fmaf(ty, r.dz, -(tz * r.dy));
+    const float cy = __builtin_fmaf(tz, r.dx, -(tx * r.dz));
+    const float cz = __builtin_fmaf(tx, r.dy, -(ty * r.dx));
+    const float d = __builtin_fmaf(r.dz, NN.z, __builtin_fmaf(r.dy, NN.y, r.dx * NN.x));
+    const float U = __builtin_fmaf(E2.z, cz, __builtin_fmaf(E2.y, cy, E2.x * cx));
+    const float a = U * d;
+    const float w1 = __builtin_fmaf(d, d, -a);
+    const float m1 = __builtin_fminf(a, w1);
+    if (__builtin_expect(__builtin_fmaf(E2.w, __builtin_fabsf(d), m1) > 0.0f, 0)) {
+        const float4 E1 = *pe1_j;
+        const float Vn = __builtin_fmaf(E1.z, cz, __builtin_fmaf(E1.y, cy, E1.x * cx));   // = -V
+        const float b = -(Vn * d);
+        const float w = w1 - b;
+        const float m = __builtin_fminf(__builtin_fminf(a, b), w);
+        if (__builtin_fmaf(V0.w, __builtin_fabsf(d), m) > 0.0f) {
+            const float T = -__builtin_fmaf(tz, NN.z, __builtin_fmaf(ty, NN.y, tx * NN.x));
+            rare_candidate<ANYHIT>(r, list_slot, tri, a, b, w, d, T, V0.w, E1.w);
+        }
+    }
 }
 
 // Makes a value opaque to the optimiser so that per-ray quantities that happen to be equal
@@ -241,6 +275,19 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
         // The rare path splits the loop body into basic blocks, which stops the compiler from
         // hoisting the next triangle's LDS reads above the current triangle's arithmetic; the
         // reads are therefore issued one triangle ahead by hand (RT_PREFETCH).
+#if RT_STAGED
+        // hot loop reads three planes; the e1 plane is read only inside the u slab
+        float4 nV0 = pv0[0], nE2 = pe2[0], nNN = pnn[0];
+#pragma unroll 2
+        for (int j = 0; j < RT_TILE; ++j) {
+            const float4 V0 = nV0, E2 = nE2, NN = nNN;
+            const int jn = (j + 1) & (RT_TILE - 1);     // last iteration re-reads entry 0 (unused)
+            nV0 = pv0[jn]; nE2 = pe2[jn]; nNN = pnn[jn];
+#pragma unroll
+            for (int r = 0; r < RT_RPL; ++r)
+                staged_pair<ANYHIT>(ray[r], A.list + slot[r] * RT_LIST_K, tri0 + j, V0, E2, NN, pe1 + j);
+        }
+#else
 #if RT_PREFETCH
         float4 nV0 = pv0[0], nE1 = pe1[0], nE2 = pe2[0], nNN = pnn[0];
 #endif
@@ -256,23 +303,6 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
             const float4 E2 = pe2[j];
             const float4 NN = pnn[j];       // form 0: aliases the e2 plane and is unused
 #endif
-#if RT_MERGED_BRANCH
-            // one exec-mask branch per triangle instead of one per pair
-            float a[RT_RPL], b[RT_RPL], w[RT_RPL], d[RT_RPL], T[RT_RPL];
-            bool pass[RT_RPL], any = false;
-#pragma unroll
-            for (int r = 0; r < RT_RPL; ++r) {
-                pass[r] = pair_test(ray[r], V0, E1, E2, NN, a[r], b[r], w[r], d[r], T[r]);
-                any = any || pass[r];
-            }
-            if (__builtin_expect(any, 0)) {
-#pragma unroll
-                for (int r = 0; r < RT_RPL; ++r)
-                    if (pass[r])
-                        rare_candidate<ANYHIT>(ray[r], A.list + slot[r] * RT_LIST_K, tri0 + j,
-                                               a[r], b[r], w[r], d[r], T[r], V0.w, E1.w);
-            }
-#else
 #pragma unroll
             for (int r = 0; r < RT_RPL; ++r) {
                 float a, b, w, d, T;
@@ -280,8 +310,8 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
                     rare_candidate<ANYHIT>(ray[r], A.list + slot[r] * RT_LIST_K, tri0 + j,
                                            a, b, w, d, T, V0.w, E1.w);
             }
-#endif
         }
+#endif
         ++tiles_done;
         __builtin_amdgcn_s_waitcnt(0);
         if (ANYHIT) {

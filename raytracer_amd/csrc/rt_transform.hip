@@ -67,7 +67,7 @@ k_pack(const double* __restrict__ x, const double* __restrict__ y, const double*
     const double et = scale * l1 * l2;
     v0[i] = make_float4((float)ax, (float)ay, (float)az, (float)eu);
     e1[i] = make_float4((float)e1x, (float)e1y, (float)e1z, (float)et);
-    e2[i] = make_float4((float)e2x, (float)e2y, (float)e2z, 0.0f);
+    e2[i] = make_float4((float)e2x, (float)e2y, (float)e2z, (float)(2.0 * eu));
     // nn = e2 x e1, so that det = e1.(D x e2) = D.nn
     nn[i] = make_float4((float)(e2y * e1z - e2z * e1y), (float)(e2z * e1x - e2x * e1z),
                         (float)(e2x * e1y - e2y * e1x), 0.0f);
