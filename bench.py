@@ -215,7 +215,6 @@ def main() -> None:
             "primary_mrays_per_s": rays_p / (wall / steps) / 1e6,
             "rays_per_frame": {"primary": rays_p, "shadow": rays_s},
             "tests_per_s": tests / (wall / steps),
-            "pct_fp32_peak_whole_frame": 100.0 * F_TEST * tests / (wall / steps) / 1e12 / (PEAK_FP32_TFLOPS * world),
             "hit_fraction_rank0": hit_frac,
             "fp64_confirmations_per_frame": tsum[8].item() / steps,
             "overflow_rays_per_frame": tsum[9].item() / steps,

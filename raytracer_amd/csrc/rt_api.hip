@@ -86,10 +86,7 @@ extern "C" int rt_sweep_config(int* form, int* tile_tris, int* rays_per_lane, in
     if (form) *form = RT_SWEEP_FORM;
     if (tile_tris) *tile_tris = RT_TILE;
     if (rays_per_lane) *rays_per_lane = RT_RPL;
-    // hot-loop flops per pair (FMA = 2), before the lazily evaluated parts:
-    //   form 0: 5 add + 12 mul + 12 fma = 41
-    //   form 1: 4 add + 8 mul + 11 fma = 34;  staged (u test first): 3 add + 6 mul + 9 fma = 27
-    if (flop_per_pair) *flop_per_pair = RT_SWEEP_FORM == 1 ? (RT_STAGED ? 27 : 34) : 41;
+    if (flop_per_pair) *flop_per_pair = RT_FLOP_PER_PAIR;
     return RT_OK;
 }
 
@@ -148,8 +145,8 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
     if (!sc) return RT_OK;
     DevBuf* bufs[] = {&sc->ox, &sc->oy, &sc->oz, &sc->ex, &sc->ey, &sc->ez, &sc->nx, &sc->ny, &sc->nz,
                       &sc->tu, &sc->tv, &sc->iA, &sc->iB, &sc->iC, &sc->iAn, &sc->iBn, &sc->iCn,
-                      &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->pv0,
-                      &sc->pe1, &sc->pe2, &sc->pnn, &sc->scratch_max, &sc->mat_dev, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf,
+                      &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes,
+                      &sc->scratch_max, &sc->mat_dev, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
                       &sc->ws_occ, &sc->ws_act0, &sc->ws_act1};
     for (DevBuf* b : bufs) b->release();
@@ -255,10 +252,7 @@ extern "C" int rt_scene_set_triangles(rt_scene* sc, int num_tris, const int* A, 
     sc->num_tris_padded = ((num_tris + RT_TILE - 1) / RT_TILE) * RT_TILE;
     if (sc->num_tris_padded == 0) sc->num_tris_padded = RT_TILE;
     const size_t pb = sizeof(float4) * (size_t)sc->num_tris_padded;
-    RT_TRY(sc->pv0.reserve(pb));
-    RT_TRY(sc->pe1.reserve(pb));
-    RT_TRY(sc->pe2.reserve(pb));
-    RT_TRY(sc->pnn.reserve(pb));
+    RT_TRY(sc->planes.reserve(pb * RT_PLANES));
     RT_TRY(sc->scratch_max.reserve(16));
     sc->transformed = false;
     return RT_OK;
@@ -510,8 +504,7 @@ extern "C" int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int
     RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
 
     SweepArgs a{};
-    a.v0 = sc->pv0.as<float4>(); a.e1 = sc->pe1.as<float4>(); a.e2 = sc->pe2.as<float4>();
-    a.nn = sc->pnn.as<float4>();
+    a.planes = sc->planes.as<float4>(); a.plane_stride = sc->num_tris_padded;
     a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
     a.W = W; a.H = H; a.y0 = y0; a.y1 = y1;
     a.ez = (double)(W / 2) / tan_half;
@@ -544,8 +537,7 @@ static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E
     RT_TRY(workspaces(sc, (size_t)n));
     RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
     SweepArgs a{};
-    a.v0 = sc->pv0.as<float4>(); a.e1 = sc->pe1.as<float4>(); a.e2 = sc->pe2.as<float4>();
-    a.nn = sc->pnn.as<float4>();
+    a.planes = sc->planes.as<float4>(); a.plane_stride = sc->num_tris_padded;
     a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
     a.W = tiledW; a.y0 = y0; a.y1 = y1; a.H = 0;
     a.n_rays = n; a.S = S; a.E = E;

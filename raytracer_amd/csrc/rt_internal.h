@@ -34,22 +34,26 @@ void rt_set_error(const char* fmt, ...);
 
 // ---------------------------------------------------------------- tunables
 constexpr int RT_WG = 256;          // threads per workgroup of every kernel here (4 waves)
+#ifndef RT_SWEEP_FORM
+#define RT_SWEEP_FORM 2     // evaluation order of the pair test, see rt_sweep.hip (0, 1 or 2)
+#endif
 #ifndef RT_TILE_TRIS
 #define RT_TILE_TRIS 128
 #endif
 #ifndef RT_RAYS_PER_LANE
-#define RT_RAYS_PER_LANE 2
+#define RT_RAYS_PER_LANE (RT_SWEEP_FORM == 2 ? 4 : 2)
 #endif
-#ifndef RT_SWEEP_FORM
-#define RT_SWEEP_FORM 1     // 0 = textbook Moller-Trumbore order, 1 = shared cross product + stored normal
+#ifndef RT_MERGED_BRANCH
+#define RT_MERGED_BRANCH 1  // form 2: one rare-path branch per triangle (all rays of a lane) instead of per pair
 #endif
-#ifndef RT_PREFETCH
-#define RT_PREFETCH 1       // issue the next triangle's LDS reads before the current arithmetic
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 1      // __launch_bounds__ waves per SIMD the sweep's register allocation must allow
 #endif
-#ifndef RT_STAGED
-#define RT_STAGED (RT_SWEEP_FORM == 1)   // lazy evaluation: u test first, V / v / u+v / T only inside the u slab
-#endif
-constexpr int RT_PLANES = RT_SWEEP_FORM == 1 ? 4 : 3;   // float4 planes staged per tile
+// float4 planes per triangle in the sweep buffer and in each LDS tile
+constexpr int RT_PLANES = RT_SWEEP_FORM == 0 ? 3 : (RT_SWEEP_FORM == 1 ? 4 : 5);
+// fp32 flops the hot loop executes per pair before the lazily evaluated parts (FMA = 2):
+//   form 0: 5 add + 12 mul + 12 fma = 41;  form 1: 3 add + 6 mul + 9 fma = 27;  form 2: 3 mul + 9 fma = 21
+constexpr int RT_FLOP_PER_PAIR = RT_SWEEP_FORM == 0 ? 41 : (RT_SWEEP_FORM == 1 ? 27 : 21);
 constexpr int RT_TILE = RT_TILE_TRIS;      // triangles per LDS tile of the sweep
 constexpr int RT_RPL = RT_RAYS_PER_LANE;   // rays per lane in the sweep
 constexpr int RT_LIST_K = 16;       // candidate slots per ray handed to the fp64 confirmation
@@ -88,9 +92,9 @@ struct rt_scene {
     std::vector<DevBuf> tex_data;
     bool has_tex_idx = false;
 
-    // fp32 sweep buffer: three float4 planes of num_tris_padded entries
-    //   v0 = (A.x, A.y, A.z, eu)   e1 = (B-A, et)   e2 = (C-A, 0)   nn = (e2 x e1, 0)
-    DevBuf pv0, pe1, pe2, pnn;
+    // fp32 sweep buffer: RT_PLANES float4 planes of num_tris_padded entries each, back to back
+    // (contents per formulation: k_pack in rt_transform.hip)
+    DevBuf planes;
     DevBuf scratch_max;         // 1 float: max |coordinate| of the eye-space vertices
     DevBuf mat_dev;             // the 4x4 of the current transform
 
@@ -138,7 +142,8 @@ int rt_launch_pack(rt_scene* sc, hipStream_t st);
 
 // rt_sweep.hip
 struct SweepArgs {
-    const float4 *v0, *e1, *e2, *nn;   // nn = e2 x e1 (only read when RT_SWEEP_FORM == 1)
+    const float4* planes;   // RT_PLANES planes, plane p starts at planes + p * plane_stride
+    long plane_stride;
     int num_tris, num_tris_padded;
     // primary mode
     int W, H, y0, y1;

@@ -3,16 +3,25 @@
 // Replaces the per-ray launch of intersect_single_triangle_device
 // (triangle_intersection.cu:31-96,145-150: one thread per triangle, one launch per ray) by
 // the inverse mapping: every lane owns RT_RPL rays and sweeps the triangles, which arrive
-// as float4 planes (v0|eu, e1|et, e2, nn) staged through LDS in tiles of RT_TILE
-// triangles that all four waves of the workgroup read at wave-uniform addresses
+// as RT_PLANES float4 planes (built by k_pack, rt_transform.hip) staged through LDS in tiles
+// of RT_TILE triangles that all four waves of the workgroup read at wave-uniform addresses
 // (LDS broadcast, no bank conflicts).
 //
-// Arithmetic per (ray, triangle) pair: the general-origin Moller-Trumbore evaluation in fp32
-// FMA -- tvec = O - v0, pvec = D x e2, det = e1.pvec, U = tvec.pvec, qvec = tvec x e1,
-// V = D.qvec, T = e2.qvec -- which is the reference's Cramer solve (:59-94) with D = E - S,
-// u = U/det, v = V/det, t = T/det.  The three divisions are replaced by sign-consistent
-// products (a = U*det, b = V*det, c = det*det), so the hot loop is 32 VALU instructions per
-// pair; T and the division are evaluated only for the rare pair that passes.
+// Per (ray, triangle) pair the kernel evaluates, in fp32 FMA, the determinants of the
+// reference's Cramer solve (:59-94).  With D = E - S, tvec = S - A, e1 = B - A, e2 = C - A:
+//     det = e1.(D x e2)     U = tvec.(D x e2)     V = D.(tvec x e1)     T = e2.(tvec x e1)
+// and u = U/det, v = V/det, t = T/det.  Three evaluation orders are kept (RT_SWEEP_FORM):
+//   0  textbook Moller-Trumbore: pvec = D x e2, qvec = tvec x e1            (31 instr / pair)
+//   1  shared cross product c = tvec x D: U = e2.c, V = -e1.c, det = D.nn with the stored
+//      normal nn = e2 x e1; lazy: u test first                              (20 instr / pair)
+//   2  moment form: by linearity in tvec = O - v0, with the ray moment M = O x D kept per ray
+//      and g = e2 x v0, h = e1 x v0, k = v0.nn stored per triangle,
+//          U = e2.M - D.g      V = D.h - e1.M      T = k - O.nn      det = D.nn
+//      lazy: u test first                                                   (14 instr / pair)
+// The divisions are replaced by sign-consistent products: with a = U*det, b = V*det,
+// w = det*det - a - b a pair is inside when min(a, b, w) >= 0.  "Lazy" is the SIMD counterpart
+// of the early returns of the reference kernel (:67-94): V, the v and u+v tests and T are only
+// evaluated where some lane of the wave is inside the u slab.
 //
 // The fp32 pass is a conservative FILTER, not the final word: a pair passes when it lies
 // inside the triangle widened by a per-triangle rounding bound (eu, et; see rt_transform.hip).
@@ -33,11 +42,15 @@ namespace {
 constexpr float RT_INF = __builtin_huge_valf();
 
 struct Ray {
+#if RT_SWEEP_FORM == 2
+    float mx, my, mz;   // moment O x D (the origin itself is re-read in the rare path)
+#else
     float ox, oy, oz;
-    float dx, dy, dz;
-    float best;      // smallest certain t so far (closest-hit mode)
-    float best_hi;   // pruning threshold: best + its error bound; -inf = ray retired/invalid
-    int cnt;         // candidates pushed so far, plus the RT_CNT_* flag bits
+#endif
+    float dx, dy, dz;   // unit direction
+    float best;         // smallest certain t so far (closest-hit mode)
+    float best_hi;      // pruning threshold: best + its error bound; -inf = ray retired/invalid
+    int cnt;            // candidates pushed so far, plus the RT_CNT_* flag bits
 };
 
 // One candidate that passed the widened barycentric test.  Rare: a few per ray per sweep.
@@ -66,87 +79,126 @@ __device__ __forceinline__ void rare_candidate(Ray& r, int32_t* __restrict__ lis
     }
 }
 
-// The pair evaluation.  Returns true when the pair needs the rare path.
-//
-// Both forms compute the same three scalar triple products
-//     det = e1.(D x e2),  U = tvec.(D x e2),  V = D.(tvec x e1)        (tvec = O - v0)
-// and defer the fourth, T = e2.(tvec x e1), to the rare path.
-//   RT_SWEEP_FORM 0: the textbook Moller-Trumbore order (pvec = D x e2, qvec = tvec x e1):
-//                    24 instructions for det, U, V.
-//   RT_SWEEP_FORM 1: one shared cross product c = tvec x D, U = e2.c, V = -e1.c, and
-//                    det = D.nn with the per-triangle nn = e2 x e1 precomputed by k_pack:
-//                    18 instructions.  T = -tvec.nn.
-// The acceptance test is division-free: with a = U*det, b = V*det, w = det*det - a - b the
-// pair passes when min(a, b, w) + eu*|det| > 0.
-[[maybe_unused]] __device__ __forceinline__ bool pair_test(const Ray& r, const float4 V0, const float4 E1,
-                                          const float4 E2, const float4 NN, float& a, float& b,
-                                          float& w, float& d, float& T)
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
 {
-    const float tx = r.ox - V0.x, ty = r.oy - V0.y, tz = r.oz - V0.z;
-#if RT_SWEEP_FORM == 0
-    const float px = __builtin_fmaf(r.dy, E2.z, -(r.dz * E2.y));
-    const float py = __builtin_fmaf(r.dz, E2.x, -(r.dx * E2.z));
-    const float pz = __builtin_fmaf(r.dx, E2.y, -(r.dy * E2.x));
-    d = __builtin_fmaf(E1.z, pz, __builtin_fmaf(E1.y, py, E1.x * px));
-    const float U = __builtin_fmaf(tz, pz, __builtin_fmaf(ty, py, tx * px));
-    const float qx = __builtin_fmaf(ty, E1.z, -(tz * E1.y));
-    const float qy = __builtin_fmaf(tz, E1.x, -(tx * E1.z));
-    const float qz = __builtin_fmaf(tx, E1.y, -(ty * E1.x));
-    const float V = __builtin_fmaf(r.dz, qz, __builtin_fmaf(r.dy, qy, r.dx * qx));
-    T = __builtin_fmaf(E2.z, qz, __builtin_fmaf(E2.y, qy, E2.x * qx));
-    (void)NN;
-    a = U * d;
-    b = V * d;
-#else
-    // c = tvec x D
-    const float cx = __builtin_fmaf(ty, r.dz, -(tz * r.dy));
-    const float cy = __builtin_fmaf(tz, r.dx, -(tx * r.dz));
-    const float cz = __builtin_fmaf(tx, r.dy, -(ty * r.dx));
-    d = __builtin_fmaf(r.dz, NN.z, __builtin_fmaf(r.dy, NN.y, r.dx * NN.x));
-    const float U = __builtin_fmaf(E2.z, cz, __builtin_fmaf(E2.y, cy, E2.x * cx));
-    const float Vn = __builtin_fmaf(E1.z, cz, __builtin_fmaf(E1.y, cy, E1.x * cx));   // = -V
-    T = -__builtin_fmaf(tz, NN.z, __builtin_fmaf(ty, NN.y, tx * NN.x));
-    a = U * d;
-    b = -(Vn * d);
-#endif
-    w = __builtin_fmaf(d, d, -a) - b;
-    const float m = __builtin_fminf(__builtin_fminf(a, b), w);      // v_min3_f32
-    return __builtin_fmaf(V0.w, __builtin_fabsf(d), m) > 0.0f;
+    return __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
 }
 
-// RT_SWEEP_FORM 1 with lazy evaluation, the SIMD counterpart of the early returns in
-// intersect_single_triangle_device (triangle_intersection.cu:67-94): the u test needs only
-// tvec, c = tvec x D, det = D.nn and U = e2.c (20 instructions with its compare).  V = -e1.c,
-// the v and u+v tests and finally T are evaluated only where some lane of the wave is inside the
-// u slab, which for coherent rays and small triangles is a few percent of the wave-pairs.
-// Tolerances: the u slab is widened by e2.w = 2*eu because u <= 1 is implied by the final
-// w >= -eu*|det| and b >= -eu*|det| only up to 2*eu*|det|.
+// ---- one pair, per formulation.  `tile` points at entry j of plane 0 of the current LDS
+// buffer; plane p of the same triangle is RT_TILE entries further per plane.
+#if RT_SWEEP_FORM == 0
+// planes: 0 = (A, eu)   1 = (e1, et)   2 = (e2, 0)
+struct Tri { float4 V0, E1, E2; };
+__device__ __forceinline__ Tri load_tri(const float4* p) { return {p[0], p[RT_TILE], p[2 * RT_TILE]}; }
+
 template <bool ANYHIT>
-__device__ __forceinline__ void staged_pair(Ray& r, int32_t* __restrict__ list_slot, int tri,
-                                            const float4 V0, const float4 E2, const float4 NN,
-                                            const float4* __restrict__ pe1_j)
+__device__ __forceinline__ void pair(Ray& r, int32_t* __restrict__ list_slot, int tri, const Tri& q,
+                                     const float4*, const double*)
 {
-    const float tx = r.ox - V0.x, ty = r.oy - V0.y, tz = r.oz - V0.z;
-    const float cx = __builtin_fmaf(ty, r.dz, -(tz * r.dy));
+    const float tx = r.ox - q.V0.x, ty = r.oy - q.V0.y, tz = r.oz - q.V0.z;
+    const float px = __builtin_fmaf(r.dy, q.E2.z, -(r.dz * q.E2.y));
+    const float py = __builtin_fmaf(r.dz, q.E2.x, -(r.dx * q.E2.z));
+    const float pz = __builtin_fmaf(r.dx, q.E2.y, -(r.dy * q.E2.x));
+    const float d = dot3(q.E1.x, q.E1.y, q.E1.z, px, py, pz);
+    const float U = dot3(tx, ty, tz, px, py, pz);
+    const float qx = __builtin_fmaf(ty, q.E1.z, -(tz * q.E1.y));
+    const float qy = __builtin_fmaf(tz, q.E1.x, -(tx * q.E1.z));
+    const float qz = __builtin_fmaf(tx, q.E1.y, -(ty * q.E1.x));
+    const float V = dot3(r.dx, r.dy, r.dz, qx, qy, qz);
+    const float a = U * d, b = V * d;
+    const float w = __builtin_fmaf(d, d, -a) - b;
+    const float m = __builtin_fminf(__builtin_fminf(a, b), w);      // v_min3_f32
+    if (__builtin_expect(__builtin_fmaf(q.V0.w, __builtin_fabsf(d), m) > 0.0f, 0)) {
+        const float T = dot3(q.E2.x, q.E2.y, q.E2.z, qx, qy, qz);
+        rare_candidate<ANYHIT>(r, list_slot, tri, a, b, w, d, T, q.V0.w, q.E1.w);
+    }
+}
+#elif RT_SWEEP_FORM == 1
+// planes: 0 = (A, eu)   1 = (e2, 2eu)   2 = (nn, 0)   3 = (e1, et)      [3: u slab only]
+struct Tri { float4 V0, E2, NN; };
+__device__ __forceinline__ Tri load_tri(const float4* p) { return {p[0], p[RT_TILE], p[2 * RT_TILE]}; }
+
+template <bool ANYHIT>
+__device__ __forceinline__ void pair(Ray& r, int32_t* __restrict__ list_slot, int tri, const Tri& q,
+                                     const float4* __restrict__ p, const double*)
+{
+    const float tx = r.ox - q.V0.x, ty = r.oy - q.V0.y, tz = r.oz - q.V0.z;
+    const float cx = __builtin_fmaf(ty, r.dz, -(tz * r.dy));       // c = tvec x D
     const float cy = __builtin_fmaf(tz, r.dx, -(tx * r.dz));
     const float cz = __builtin_fmaf(tx, r.dy, -(ty * r.dx));
-    const float d = __builtin_fmaf(r.dz, NN.z, __builtin_fmaf(r.dy, NN.y, r.dx * NN.x));
-    const float U = __builtin_fmaf(E2.z, cz, __builtin_fmaf(E2.y, cy, E2.x * cx));
+    const float d = dot3(r.dx, r.dy, r.dz, q.NN.x, q.NN.y, q.NN.z);
+    const float U = dot3(q.E2.x, q.E2.y, q.E2.z, cx, cy, cz);
     const float a = U * d;
     const float w1 = __builtin_fmaf(d, d, -a);
-    const float m1 = __builtin_fminf(a, w1);
-    if (__builtin_expect(__builtin_fmaf(E2.w, __builtin_fabsf(d), m1) > 0.0f, 0)) {
-        const float4 E1 = *pe1_j;
-        const float Vn = __builtin_fmaf(E1.z, cz, __builtin_fmaf(E1.y, cy, E1.x * cx));   // = -V
-        const float b = -(Vn * d);
+    // u slab, widened by 2*eu: u <= 1 follows from w >= -eu|d| and b >= -eu|d| only up to 2*eu|d|
+    if (__builtin_expect(__builtin_fmaf(q.E2.w, __builtin_fabsf(d), __builtin_fminf(a, w1)) > 0.0f, 0)) {
+        const float4 E1 = p[3 * RT_TILE];
+        const float b = dot3(E1.x, E1.y, E1.z, cx, cy, cz) * -d;   // V = -e1.c
         const float w = w1 - b;
         const float m = __builtin_fminf(__builtin_fminf(a, b), w);
-        if (__builtin_fmaf(V0.w, __builtin_fabsf(d), m) > 0.0f) {
-            const float T = -__builtin_fmaf(tz, NN.z, __builtin_fmaf(ty, NN.y, tx * NN.x));
-            rare_candidate<ANYHIT>(r, list_slot, tri, a, b, w, d, T, V0.w, E1.w);
+        if (__builtin_fmaf(q.V0.w, __builtin_fabsf(d), m) > 0.0f) {
+            const float T = -dot3(tx, ty, tz, q.NN.x, q.NN.y, q.NN.z);
+            rare_candidate<ANYHIT>(r, list_slot, tri, a, b, w, d, T, q.V0.w, E1.w);
         }
     }
 }
+#else
+// planes: 0 = (nn, 2eu)   1 = (g = e2 x v0, eu)   2 = (e2, et)   3 = (e1, k = v0.nn)
+//         4 = (h = e1 x v0, 0)                                          [3, 4: u slab only]
+struct Tri { float4 NN, G, E2; };
+__device__ __forceinline__ Tri load_tri(const float4* p) { return {p[0], p[RT_TILE], p[2 * RT_TILE]}; }
+
+// u-slab test of one pair: 14 VALU instructions.
+__device__ __forceinline__ bool in_u_slab(const Ray& r, const Tri& q, float& d, float& a, float& w1)
+{
+    d = dot3(r.dx, r.dy, r.dz, q.NN.x, q.NN.y, q.NN.z);
+    // U = e2.M - D.g, one six-term FMA chain
+    float U = r.mx * q.E2.x;
+    U = __builtin_fmaf(r.my, q.E2.y, U);
+    U = __builtin_fmaf(r.mz, q.E2.z, U);
+    U = __builtin_fmaf(-r.dx, q.G.x, U);
+    U = __builtin_fmaf(-r.dy, q.G.y, U);
+    U = __builtin_fmaf(-r.dz, q.G.z, U);
+    a = U * d;
+    w1 = __builtin_fmaf(d, d, -a);
+    return __builtin_fmaf(q.NN.w, __builtin_fabsf(d), __builtin_fminf(a, w1)) > 0.0f;
+}
+
+// The rest of the test for a pair inside the u slab (a few percent of the wave-pairs).
+template <bool ANYHIT>
+__device__ __forceinline__ void finish_pair(Ray& r, int32_t* __restrict__ list_slot, int tri,
+                                            const Tri& q, const float4* __restrict__ p,
+                                            const double* __restrict__ origin, float d, float a,
+                                            float w1)
+{
+    const float4 E1 = p[3 * RT_TILE], H = p[4 * RT_TILE];
+    float V = r.dx * H.x;                                       // V = D.h - e1.M
+    V = __builtin_fmaf(r.dy, H.y, V);
+    V = __builtin_fmaf(r.dz, H.z, V);
+    V = __builtin_fmaf(-r.mx, E1.x, V);
+    V = __builtin_fmaf(-r.my, E1.y, V);
+    V = __builtin_fmaf(-r.mz, E1.z, V);
+    const float b = V * d;
+    const float w = w1 - b;
+    const float m = __builtin_fminf(__builtin_fminf(a, b), w);
+    if (__builtin_fmaf(q.G.w, __builtin_fabsf(d), m) > 0.0f) {
+        // T = k - O.nn; the origin is not kept in registers (primary rays: O = 0)
+        float ox = 0.0f, oy = 0.0f, oz = 0.0f;
+        if (origin) { ox = (float)origin[0]; oy = (float)origin[1]; oz = (float)origin[2]; }
+        const float T = E1.w - dot3(ox, oy, oz, q.NN.x, q.NN.y, q.NN.z);
+        rare_candidate<ANYHIT>(r, list_slot, tri, a, b, w, d, T, q.G.w, q.E2.w);
+    }
+}
+
+template <bool ANYHIT>
+__device__ __forceinline__ void pair(Ray& r, int32_t* __restrict__ list_slot, int tri, const Tri& q,
+                                     const float4* __restrict__ p, const double* __restrict__ origin)
+{
+    float d, a, w1;
+    if (__builtin_expect(in_u_slab(r, q, d, a, w1), 0))
+        finish_pair<ANYHIT>(r, list_slot, tri, q, p, origin, d, a, w1);
+}
+#endif
 
 // Makes a value opaque to the optimiser so that per-ray quantities that happen to be equal
 // in every lane (the shared origin of primary rays) are still carried and used per ray.
@@ -159,9 +211,9 @@ __device__ __forceinline__ float opaque(float x)
 enum { MODE_PRIMARY = 0, MODE_RAYS_LINEAR = 1, MODE_RAYS_TILED = 2, MODE_RAYS_INDEXED = 3 };
 
 template <int MODE, bool ANYHIT>
-__global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
+__global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep(const SweepArgs A)
 {
-    // double-buffered v0/e1/e2 planes of one tile
+    // double-buffered planes of one tile
     __shared__ float4 tile[2][RT_PLANES][RT_TILE];
 
     const int tid = threadIdx.x;
@@ -169,7 +221,7 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
     const int wave = tid >> 6;
 
     Ray ray[RT_RPL];
-    long slot[RT_RPL];        // index into cnt[] / list[] (band-local pixel or ray number)
+    int slot[RT_RPL];         // index into cnt[] / list[] (band-local pixel or ray number, < 2^31)
     bool in_range[RT_RPL];
 
     // ---- ray set-up ------------------------------------------------------------------
@@ -180,11 +232,11 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
         if (MODE == MODE_RAYS_LINEAR) {
             const long j = (long)blockIdx.x * RT_RAYS_PER_WG + r * RT_WG + tid;
             valid = j < A.n_rays;
-            slot[r] = j;
+            slot[r] = valid ? (int)j : 0;
         } else if (MODE == MODE_RAYS_INDEXED) {
             const long j = (long)blockIdx.x * RT_RAYS_PER_WG + r * RT_WG + tid;
             valid = j < A.n_rays;
-            slot[r] = valid ? (long)A.active[j] : 0;
+            slot[r] = valid ? A.active[j] : 0;
         } else {
             // workgroup = RT_TILE_W x RT_TILE_H pixels; wave = (8*RPL) x 8; lane = 8 x 8
             const int tiles_x = (A.W + RT_TILE_W - 1) / RT_TILE_W;
@@ -193,7 +245,7 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
             const int py = A.y0 + tyi * RT_TILE_H + (wave >> 1) * 8 + (lane >> 3);
             valid = (px < A.W) && (py < A.y1);
             const long npix = (long)A.W * (A.y1 - A.y0);
-            slot[r] = (long)blockIdx.y * npix + (long)(py - A.y0) * A.W + px;
+            slot[r] = valid ? (int)((long)blockIdx.y * npix + (long)(py - A.y0) * A.W + px) : 0;
             if (MODE == MODE_PRIMARY) {
                 // driver.c:131-133 with S = origin = 0 (driver.c:121-123)
                 Ex = (double)(px - A.W / 2);
@@ -203,23 +255,32 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
         }
         in_range[r] = valid;
         if (MODE != MODE_PRIMARY && valid) {
-            const double* s = A.S + 3 * slot[r];
-            const double* e = A.E + 3 * slot[r];
+            const double* s = A.S + 3 * (long)slot[r];
+            const double* e = A.E + 3 * (long)slot[r];
             Sx = s[0]; Sy = s[1]; Sz = s[2];
             Ex = e[0]; Ey = e[1]; Ez = e[2];
             if (!(Sx == Sx)) valid = false;       // NaN origin marks an unused ray slot
         }
         // D is normalised: t scales by |D| for every triangle alike, so the per-ray order of
         // candidates is unchanged and the per-triangle error bounds need no |D| factor.
-        const double Dx = Ex - Sx, Dy = Ey - Sy, Dz = Ez - Sz;
+        double Dx = Ex - Sx, Dy = Ey - Sy, Dz = Ez - Sz;
         const double inv = 1.0 / __builtin_sqrt(Dx * Dx + Dy * Dy + Dz * Dz);
         if (!(inv == inv) || inv > 1e300) valid = false;      // zero-length ray hits nothing
-        ray[r].ox = opaque(valid ? (float)Sx : 0.0f);
-        ray[r].oy = opaque(valid ? (float)Sy : 0.0f);
-        ray[r].oz = opaque(valid ? (float)Sz : 0.0f);
-        ray[r].dx = valid ? (float)(Dx * inv) : 0.0f;
-        ray[r].dy = valid ? (float)(Dy * inv) : 0.0f;
-        ray[r].dz = valid ? (float)(Dz * inv) : 0.0f;
+        if (!valid) { Sx = Sy = Sz = 0; Dx = Dy = Dz = 0; } else { Dx *= inv; Dy *= inv; Dz *= inv; }
+        ray[r].dx = (float)Dx;
+        ray[r].dy = (float)Dy;
+        ray[r].dz = (float)Dz;
+#if RT_SWEEP_FORM == 2
+        // moment in fp64 from the fp64 ray, rounded once; opaque so that primary rays (M = 0 in
+        // every lane) still execute the general test
+        ray[r].mx = opaque((float)(Sy * Dz - Sz * Dy));
+        ray[r].my = opaque((float)(Sz * Dx - Sx * Dz));
+        ray[r].mz = opaque((float)(Sx * Dy - Sy * Dx));
+#else
+        ray[r].ox = opaque((float)Sx);
+        ray[r].oy = opaque((float)Sy);
+        ray[r].oz = opaque((float)Sz);
+#endif
         ray[r].best = RT_INF;
         ray[r].best_hi = valid ? RT_INF : -RT_INF;
         ray[r].cnt = valid ? 0 : RT_CNT_RETIRED;
@@ -233,27 +294,17 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
     // ---- tile loop -------------------------------------------------------------------
     const int t_begin = A.tri_begin / RT_TILE, t_end = A.tri_end / RT_TILE;
     auto stage = [&](int t, int buf) {
-        // 3 planes x RT_TILE float4; one LDS-DMA instruction moves 64 float4 (1 KiB) per wave:
+        // RT_PLANES x RT_TILE float4; one LDS-DMA instruction moves 64 float4 (1 KiB) per wave:
         // global source per lane, LDS destination = wave-uniform base + 16 * lane.
 #pragma unroll
-        for (int c = 0; c < (RT_TILE / 64 + 3) / 4; ++c) {
-            const int chunk = c * 4 + wave;
-            if (chunk < RT_TILE / 64) {
-                const long g = (long)t * RT_TILE + chunk * 64 + lane;
+        for (int c = 0; c < (RT_PLANES * (RT_TILE / 64) + 3) / 4; ++c) {
+            const int chunk = c * 4 + wave;                 // chunk = plane * (RT_TILE/64) + part
+            if (chunk < RT_PLANES * (RT_TILE / 64)) {
+                const int plane = chunk / (RT_TILE / 64), part = chunk % (RT_TILE / 64);
+                const long g = (long)plane * A.plane_stride + (long)t * RT_TILE + part * 64 + lane;
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(A.v0 + g),
-                    (__attribute__((address_space(3))) void*)&tile[buf][0][chunk * 64], 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(A.e1 + g),
-                    (__attribute__((address_space(3))) void*)&tile[buf][1][chunk * 64], 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(A.e2 + g),
-                    (__attribute__((address_space(3))) void*)&tile[buf][2][chunk * 64], 16, 0, 0);
-#if RT_SWEEP_FORM == 1
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(A.nn + g),
-                    (__attribute__((address_space(3))) void*)&tile[buf][3][chunk * 64], 16, 0, 0);
-#endif
+                    (const __attribute__((address_space(1))) void*)(A.planes + g),
+                    (__attribute__((address_space(3))) void*)&tile[buf][plane][part * 64], 16, 0, 0);
             }
         }
     };
@@ -267,51 +318,42 @@ __global__ void __launch_bounds__(RT_WG) k_sweep(const SweepArgs A)
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
         if (t + 1 < t_end) stage(t + 1, buf ^ 1);
-        const float4* __restrict__ pv0 = tile[buf][0];
-        const float4* __restrict__ pe1 = tile[buf][1];
-        const float4* __restrict__ pe2 = tile[buf][2];
-        const float4* __restrict__ pnn = tile[buf][RT_PLANES - 1];
+        const float4* __restrict__ base = tile[buf][0];
         const int tri0 = t * RT_TILE;
         // The rare path splits the loop body into basic blocks, which stops the compiler from
         // hoisting the next triangle's LDS reads above the current triangle's arithmetic; the
-        // reads are therefore issued one triangle ahead by hand (RT_PREFETCH).
-#if RT_STAGED
-        // hot loop reads three planes; the e1 plane is read only inside the u slab
-        float4 nV0 = pv0[0], nE2 = pe2[0], nNN = pnn[0];
+        // reads are therefore issued one triangle ahead by hand.
+        Tri next = load_tri(base);
 #pragma unroll 2
         for (int j = 0; j < RT_TILE; ++j) {
-            const float4 V0 = nV0, E2 = nE2, NN = nNN;
-            const int jn = (j + 1) & (RT_TILE - 1);     // last iteration re-reads entry 0 (unused)
-            nV0 = pv0[jn]; nE2 = pe2[jn]; nNN = pnn[jn];
-#pragma unroll
-            for (int r = 0; r < RT_RPL; ++r)
-                staged_pair<ANYHIT>(ray[r], A.list + slot[r] * RT_LIST_K, tri0 + j, V0, E2, NN, pe1 + j);
-        }
-#else
-#if RT_PREFETCH
-        float4 nV0 = pv0[0], nE1 = pe1[0], nE2 = pe2[0], nNN = pnn[0];
-#endif
-#pragma unroll 2
-        for (int j = 0; j < RT_TILE; ++j) {
-#if RT_PREFETCH
-            const float4 V0 = nV0, E1 = nE1, E2 = nE2, NN = nNN;
-            const int jn = (j + 1) & (RT_TILE - 1);     // last iteration re-reads entry 0 (unused)
-            nV0 = pv0[jn]; nE1 = pe1[jn]; nE2 = pe2[jn]; nNN = pnn[jn];
-#else
-            const float4 V0 = pv0[j];
-            const float4 E1 = pe1[j];
-            const float4 E2 = pe2[j];
-            const float4 NN = pnn[j];       // form 0: aliases the e2 plane and is unused
-#endif
+            const Tri cur = next;
+            next = load_tri(base + ((j + 1) & (RT_TILE - 1)));      // last iteration re-reads entry 0 (unused)
+#if RT_SWEEP_FORM == 2 && RT_MERGED_BRANCH
+            // one exec-mask branch per triangle for all rays of the lane; the slab quantities
+            // are recomputed inside (rare) so that only the predicates stay live across it
+            bool in[RT_RPL], any = false;
 #pragma unroll
             for (int r = 0; r < RT_RPL; ++r) {
-                float a, b, w, d, T;
-                if (__builtin_expect(pair_test(ray[r], V0, E1, E2, NN, a, b, w, d, T), 0))
-                    rare_candidate<ANYHIT>(ray[r], A.list + slot[r] * RT_LIST_K, tri0 + j,
-                                           a, b, w, d, T, V0.w, E1.w);
+                float d, a, w1;
+                in[r] = in_u_slab(ray[r], cur, d, a, w1);
+                any = any || in[r];
             }
-        }
+            if (__builtin_expect(any, 0)) {
+#pragma unroll
+                for (int r = 0; r < RT_RPL; ++r) {
+                    float d, a, w1;
+                    if (in[r] && in_u_slab(ray[r], cur, d, a, w1))
+                        finish_pair<ANYHIT>(ray[r], A.list + (long)slot[r] * RT_LIST_K, tri0 + j, cur, base + j,
+                                            MODE == MODE_PRIMARY ? nullptr : A.S + 3 * (long)slot[r], d, a, w1);
+                }
+            }
+#else
+#pragma unroll
+            for (int r = 0; r < RT_RPL; ++r)
+                pair<ANYHIT>(ray[r], A.list + (long)slot[r] * RT_LIST_K, tri0 + j, cur, base + j,
+                             MODE == MODE_PRIMARY ? nullptr : A.S + 3 * (long)slot[r]);
 #endif
+        }
         ++tiles_done;
         __builtin_amdgcn_s_waitcnt(0);
         if (ANYHIT) {
@@ -370,12 +412,12 @@ int launch(const SweepArgs& a, dim3 grid, hipStream_t st)
 
 static int check_common(const SweepArgs& a)
 {
-    if (!a.v0 || !a.e1 || !a.e2 || !a.nn || !a.cnt || !a.list) {
+    if (!a.planes || !a.cnt || !a.list) {
         rt_set_error("sweep: null buffer");
         return RT_E_ARG;
     }
     if (a.num_tris_padded <= 0 || a.num_tris_padded % RT_TILE != 0 ||
-        a.num_tris > a.num_tris_padded) {
+        a.num_tris > a.num_tris_padded || a.plane_stride < a.num_tris_padded) {
         rt_set_error("sweep: triangle planes must be padded to a multiple of %d", RT_TILE);
         return RT_E_ARG;
     }

@@ -5,9 +5,10 @@
 // fully coalesced (24 B in, 24 B out per point).  It is compiled without FMA contraction so
 // the result equals the host twin M3d_mat_mult_points (M3d_matrix_tools.c:184-208) bit for bit.
 //
-// k_pack derives, per triangle, what the sweep consumes: v0 = A, e1 = B-A, e2 = C-A
-// (differences taken in fp64, then rounded once to fp32) plus two rounding bounds that make
-// the fp32 test a conservative filter (see rt_sweep.hip):
+// k_pack derives, per triangle, what the sweep consumes -- v0 = A, e1 = B-A, e2 = C-A and,
+// depending on the formulation, nn = e2 x e1, g = e2 x v0, h = e1 x v0, k = v0.nn (everything
+// formed in fp64, then rounded once to fp32) -- plus two rounding bounds that make the fp32
+// test a conservative filter (see rt_sweep.hip):
 //     eu bounds |error of U*, V*, det-U-V| for a unit-length ray direction,
 //     et bounds |error of T|,
 // both proportional to 2^-20 * (4 * largest |coordinate| in eye space) * edge lengths.
@@ -44,16 +45,16 @@ __global__ void __launch_bounds__(RT_WG)
 k_pack(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
        const int* __restrict__ iA, const int* __restrict__ iB, const int* __restrict__ iC,
        int num_tris, int num_tris_padded, const unsigned* __restrict__ max_bits,
-       float4* __restrict__ v0, float4* __restrict__ e1, float4* __restrict__ e2,
-       float4* __restrict__ nn)
+       float4* __restrict__ planes)
 {
     const int i = blockIdx.x * RT_WG + threadIdx.x;
     if (i >= num_tris_padded) return;
+    float4* p[RT_PLANES];
+#pragma unroll
+    for (int k = 0; k < RT_PLANES; ++k) p[k] = planes + (long)k * num_tris_padded + i;
     if (i >= num_tris) {        // padding: a null triangle can never pass the filter
-        v0[i] = make_float4(0, 0, 0, 0);
-        e1[i] = make_float4(0, 0, 0, 0);
-        e2[i] = make_float4(0, 0, 0, 0);
-        nn[i] = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < RT_PLANES; ++k) *p[k] = make_float4(0, 0, 0, 0);
         return;
     }
     const int a = iA[i], b = iB[i], c = iC[i];
@@ -63,14 +64,32 @@ k_pack(const double* __restrict__ x, const double* __restrict__ y, const double*
     const double l1 = sqrt(e1x * e1x + e1y * e1y + e1z * e1z);
     const double l2 = sqrt(e2x * e2x + e2y * e2y + e2z * e2z);
     const double scale = 4.0 * (double)__uint_as_float(*max_bits) * 9.5367431640625e-07;  // 2^-20
-    const double eu = 3.0 * scale * fmax(l1, l2);
-    const double et = scale * l1 * l2;
-    v0[i] = make_float4((float)ax, (float)ay, (float)az, (float)eu);
-    e1[i] = make_float4((float)e1x, (float)e1y, (float)e1z, (float)et);
-    e2[i] = make_float4((float)e2x, (float)e2y, (float)e2z, (float)(2.0 * eu));
+    const float eu = (float)(3.0 * scale * fmax(l1, l2));
+    const float eu2 = (float)(6.0 * scale * fmax(l1, l2));
+    const float et = (float)(scale * l1 * l2);
     // nn = e2 x e1, so that det = e1.(D x e2) = D.nn
-    nn[i] = make_float4((float)(e2y * e1z - e2z * e1y), (float)(e2z * e1x - e2x * e1z),
-                        (float)(e2x * e1y - e2y * e1x), 0.0f);
+    const double nx = e2y * e1z - e2z * e1y, ny = e2z * e1x - e2x * e1z, nz = e2x * e1y - e2y * e1x;
+#if RT_SWEEP_FORM == 0
+    *p[0] = make_float4((float)ax, (float)ay, (float)az, eu);
+    *p[1] = make_float4((float)e1x, (float)e1y, (float)e1z, et);
+    *p[2] = make_float4((float)e2x, (float)e2y, (float)e2z, 0.0f);
+    (void)eu2; (void)nx; (void)ny; (void)nz;
+#elif RT_SWEEP_FORM == 1
+    *p[0] = make_float4((float)ax, (float)ay, (float)az, eu);
+    *p[1] = make_float4((float)e2x, (float)e2y, (float)e2z, eu2);
+    *p[2] = make_float4((float)nx, (float)ny, (float)nz, 0.0f);
+    *p[3] = make_float4((float)e1x, (float)e1y, (float)e1z, et);
+#else
+    // moment form: g = e2 x v0, h = e1 x v0, k = v0.nn -- all formed in fp64, rounded once
+    const double gx = e2y * az - e2z * ay, gy = e2z * ax - e2x * az, gz = e2x * ay - e2y * ax;
+    const double hx = e1y * az - e1z * ay, hy = e1z * ax - e1x * az, hz = e1x * ay - e1y * ax;
+    const double k = ax * nx + ay * ny + az * nz;
+    *p[0] = make_float4((float)nx, (float)ny, (float)nz, eu2);
+    *p[1] = make_float4((float)gx, (float)gy, (float)gz, eu);
+    *p[2] = make_float4((float)e2x, (float)e2y, (float)e2z, et);
+    *p[3] = make_float4((float)e1x, (float)e1y, (float)e1z, (float)k);
+    *p[4] = make_float4((float)hx, (float)hy, (float)hz, 0.0f);
+#endif
 }
 
 }  // namespace
@@ -95,8 +114,7 @@ int rt_launch_pack(rt_scene* sc, hipStream_t st)
     hipLaunchKernelGGL(k_pack, dim3((np + RT_WG - 1) / RT_WG), dim3(RT_WG), 0, st,
                        sc->ex.as<double>(), sc->ey.as<double>(), sc->ez.as<double>(),
                        sc->iA.as<int>(), sc->iB.as<int>(), sc->iC.as<int>(), sc->num_tris, np,
-                       sc->scratch_max.as<unsigned>(), sc->pv0.as<float4>(), sc->pe1.as<float4>(),
-                       sc->pe2.as<float4>(), sc->pnn.as<float4>());
+                       sc->scratch_max.as<unsigned>(), sc->planes.as<float4>());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("pack launch failed: %s", hipGetErrorString(e));
