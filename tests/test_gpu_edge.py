@@ -1,0 +1,239 @@
+"""Edge cases of the HIP path through the C ABI: ragged image sizes, tiny and empty inputs,
+degenerate geometry, candidate-list overflow, textures, light-count extremes, error codes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from raytracer_amd import _lib, kernel, scenes
+from conftest import TAN_HALF
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(mesh, fr, W, H, **kw):
+    X, Y, Z = O.transform(mesh, kernel.frame_matrix(fr, "obmat"))
+    return O.render_rows(O.Scene(mesh, X, Y, Z), O.frame_from(fr), W, H, TAN_HALF, **kw), (X, Y, Z)
+
+
+def _gpu(mesh, fr, W, H, **kw):
+    sc = kernel.Scene(mesh)
+    sc.transform(kernel.frame_matrix(fr, "obmat"))
+    out = sc.render_rows(fr, W, H, TAN_HALF, **kw)
+    return sc, {k: v.cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (7, 5), (65, 17), (70, 37), (129, 33), (31, 250)])
+def test_ragged_image_sizes(W, H):
+    """Sizes that are not multiples of the 64x16 workgroup tile, down to a single pixel."""
+    mesh = scenes.torus(300)
+    fr = kernel.driver_frame(2)
+    ref, _ = _ref(mesh, fr, W, H)
+    sc, out = _gpu(mesh, fr, W, H)
+    assert np.array_equal(out["hit"], ref["hit"])
+    assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    sc.close()
+
+
+@pytest.mark.parametrize("ntris", [1, 2, 127, 128, 129, 257])
+def test_triangle_counts_around_the_tile_size(ntris):
+    mesh = scenes.triangle_soup(ntris, seed=ntris)
+    fr = kernel.driver_frame(0)
+    W, H = 80, 60
+    ref, _ = _ref(mesh, fr, W, H)
+    sc, out = _gpu(mesh, fr, W, H)
+    assert np.array_equal(out["hit"], ref["hit"])
+    m = ref["hit"] >= 0
+    assert np.array_equal(out["tuv"][m], ref["tuv"][m])
+    assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    sc.close()
+
+
+def test_empty_inputs_and_zero_rays():
+    mesh = scenes.torus(100)
+    fr = kernel.driver_frame(0)
+    sc = kernel.Scene(mesh)
+    sc.transform(kernel.frame_matrix(fr, "obmat"))
+    hit, tuv, point = sc.trace_rays(np.zeros((0, 3)), np.zeros((0, 3)))
+    assert hit.numel() == 0
+    assert sc.occluded(np.zeros((0, 3)), np.zeros((0, 3))).numel() == 0
+    # zero-length rays and unused (NaN-origin) slots hit nothing
+    S = np.array([[0.0, 0, 0], [np.nan, 0, 0], [1.0, 2, 3]])
+    E = np.array([[0.0, 0, 0], [0.0, 0, 1], [1.0, 2, 3]])
+    hit, _, _ = sc.trace_rays(S, E)
+    assert hit.cpu().tolist() == [-1, -1, -1]
+    assert sc.occluded(S, E).cpu().tolist() == [0, 0, 0]
+    sc.close()
+    # a scene with zero triangles renders the miss colour everywhere (driver.c:136-139)
+    empty = scenes.torus(100)
+    for k in ("A", "B", "C", "An", "Bn", "Cn"):
+        setattr(empty, k, np.zeros(0, np.int32))
+    sc2 = kernel.Scene(empty)
+    sc2.transform(kernel.frame_matrix(fr, "obmat"))
+    out = sc2.render_rows(fr, 20, 10, TAN_HALF)
+    assert torch.all(out["hit"] == -1) and torch.all(out["rgb8"] == 127)
+    sc2.close()
+
+
+def test_degenerate_and_duplicate_triangles():
+    """Zero-area triangles never hit (den == 0, triangle_intersection.cu:67); exact duplicates
+    tie and the lowest index wins (:169)."""
+    base = scenes.torus(200)
+    m = base.copy()
+    n = m.num_tris
+    # append: 10 degenerate (A == B) and a duplicate of every 7th triangle, BEFORE and AFTER
+    dup = np.arange(0, n, 7, dtype=np.int32)
+    def cat(a, extra_front, extra_back):
+        return np.ascontiguousarray(np.concatenate([extra_front, a, extra_back]).astype(np.int32))
+    deg = m.A[:10]
+    m.A, m.B, m.C = cat(m.A, m.A[dup], deg), cat(m.B, m.B[dup], deg), cat(m.C, m.C[dup], m.C[:10])
+    m.An, m.Bn, m.Cn = cat(m.An, m.An[dup], m.An[:10]), cat(m.Bn, m.Bn[dup], m.Bn[:10]), cat(m.Cn, m.Cn[dup], m.Cn[:10])
+    fr = kernel.driver_frame(6)
+    W, H = 96, 72
+    ref, _ = _ref(m, fr, W, H)
+    sc, out = _gpu(m, fr, W, H)
+    assert np.array_equal(out["hit"], ref["hit"])
+    hits = ref["hit"][ref["hit"] >= 0]
+    assert hits.max() < len(dup) + n                 # never a degenerate one
+    assert (hits < len(dup)).any()                   # front duplicates beat their originals
+    sc.close()
+
+
+def test_candidate_list_overflow_falls_back_to_full_fp64_sweep():
+    """40 coincident triangles: more candidates than list slots -> the ray is re-swept in fp64
+    (closest hit) / resolved by the full any-hit sweep, still with the reference's answer."""
+    pts = np.array([[0, 0, 0], [-3, -3, 12.0], [5, -3, 12.0], [-3, 5, 12.0],
+                    [-3, -3, 20.0], [5, -3, 20.0], [-3, 5, 20.0]], float)
+    k = 40
+    A = np.array([4] * 3 + [1] * k, np.int32)        # three far copies first, then the near stack
+    B = np.array([5] * 3 + [2] * k, np.int32)
+    Cc = np.array([6] * 3 + [3] * k, np.int32)
+    nrm = np.array([[0, 0, 0], [0, 0, -1.0]])
+    one = np.ones(len(A), np.int32)
+    mesh = scenes.Mesh(x=pts[:, 0].copy(), y=pts[:, 1].copy(), z=pts[:, 2].copy(),
+                       xn=nrm[:, 0].copy(), yn=nrm[:, 1].copy(), zn=nrm[:, 2].copy(),
+                       A=A, B=B, C=Cc, An=one, Bn=one.copy(), Cn=one.copy())
+    sc = kernel.Scene(mesh)
+    sc.transform(np.eye(4))
+    osc = O.Scene(mesh)
+    rng = np.random.default_rng(0)
+    S = np.zeros((64, 3))
+    E = np.stack([rng.uniform(-0.1, 0.1, 64), rng.uniform(-0.1, 0.1, 64), np.ones(64)], 1)
+    kernel.profile_enable(True)
+    kernel.profile_reset()
+    hit, tuv, _ = sc.trace_rays(S, E)
+    occ = sc.occluded(S, E)
+    prof = kernel.profile_get()
+    kernel.profile_enable(False)
+    assert prof.exact_overflow >= 32                 # the fallback really ran for most rays
+    nhit = 0
+    for i in range(64):
+        idx, t, uv, _ = O.intersect(osc, S[i], E[i])
+        assert hit[i].item() == idx and idx in (3, -1)   # 3 = lowest index of the nearest stack
+        assert occ[i].item() == (1 if idx != -1 else 0)
+        if idx != -1:
+            nhit += 1
+            assert tuv[i, 0].item() == t
+    assert nhit >= 32
+    sc.close()
+
+
+def test_textured_materials():
+    """map_Ka/Kd/Ks lookups (graphic_tools.c:161-197): nearest texel, v flipped."""
+    rng = np.random.default_rng(5)
+    mesh = scenes.torus(400, with_uv=True)
+    tex0 = rng.integers(0, 256, size=(16, 32, 3), dtype=np.uint8)
+    tex1 = rng.integers(0, 256, size=(9, 5, 3), dtype=np.uint8)
+    mesh.textures = [tex0, tex1]
+    mesh.Ka = np.array([[0.2, 0.3, 0.4], [1.0, 1.0, 1.0]])
+    mesh.Kd = np.array([[0.9, 0.8, 0.7], [0.5, 0.5, 0.5]])
+    mesh.Ks = np.array([[0.1, 0.2, 0.3], [1.0, 0.0, 1.0]])
+    mesh.map_Ka = np.array([-1, 1], np.int32)
+    mesh.map_Kd = np.array([0, -1], np.int32)
+    mesh.map_Ks = np.array([-1, 0], np.int32)
+    mesh.mtl = (np.arange(mesh.num_tris) % 3 - 1).astype(np.int32)     # -1, 0, 1, ...
+    fr = kernel.driver_frame(8)
+    W, H = 96, 72
+    ref, _ = _ref(mesh, fr, W, H)
+    sc, out = _gpu(mesh, fr, W, H)
+    assert np.array_equal(out["hit"], ref["hit"])
+    assert np.abs(out["argb"] - ref["argb"]).max() < 1e-9
+    assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    used = set(mesh.mtl[ref["hit"][ref["hit"] >= 0]].tolist())
+    assert used == {-1, 0, 1}
+    sc.close()
+
+
+@pytest.mark.parametrize("nl", [0, 1, 5])
+def test_light_counts(nl):
+    mesh = scenes.sphere(300)
+    fr = kernel.driver_frame(3)
+    rng = np.random.default_rng(nl)
+    fr.num_lights = nl
+    for i in range(nl):
+        pos = rng.uniform(-25, 25, 3)
+        for k in range(3):
+            fr.light_in_eye_space[i][k] = pos[k] + (0, 0, 18)[k]
+            fr.light_rgb[i][k] = rng.uniform(0, 1)
+        fr.light_attenuation[i][0], fr.light_attenuation[i][1] = 0.05, 0.01
+        fr.light_max_dist[i] = (30.0, 100.0)[i % 2]          # some beyond light_max_dist
+    W, H = 64, 48
+    ref, _ = _ref(mesh, fr, W, H)
+    sc, out = _gpu(mesh, fr, W, H)
+    assert np.array_equal(out["hit"], ref["hit"])
+    assert np.abs(out["argb"] - ref["argb"]).max() < 1e-9
+    assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    if nl == 0:
+        assert ref["shadow_rays"] == 0
+    sc.close()
+
+
+def test_error_codes_instead_of_faults():
+    lib = _lib.load()
+    mesh = scenes.torus(50)
+    sc = kernel.Scene(mesh)
+    hit = torch.empty(16, dtype=torch.int32, device="cuda")
+    # tracing before any transform
+    assert lib.rt_trace_primary(sc.h, 4, 4, TAN_HALF, 0, 4, hit.data_ptr(), None) == -3
+    assert b"rt_scene_transform" in lib.rt_last_error()
+    sc.transform(np.eye(4))
+    assert lib.rt_trace_primary(sc.h, 4, 4, TAN_HALF, 3, 2, hit.data_ptr(), None) == -1      # empty band
+    assert lib.rt_trace_primary(sc.h, 4, 4, TAN_HALF, 0, 5, hit.data_ptr(), None) == -1      # band past H
+    assert lib.rt_trace_primary(sc.h, 4, 4, -1.0, 0, 4, hit.data_ptr(), None) == -1
+    assert lib.rt_trace_primary(sc.h, 4, 4, TAN_HALF, 0, 4, None, None) == -1
+    assert lib.rt_trace_rays(sc.h, -1, None, None, None, None, None) == -1
+    # out-of-range indices are rejected at upload, never seen by a kernel
+    bad = mesh.A.copy()
+    bad[3] = mesh.num_v + 5
+    rc = lib.rt_scene_set_triangles(sc.h, mesh.num_tris, bad.ctypes.data_as(_lib.c_int_p),
+                                    mesh.B.ctypes.data_as(_lib.c_int_p), mesh.C.ctypes.data_as(_lib.c_int_p),
+                                    None, None, None, None, None, None, None)
+    assert rc == -1 and b"vertex index" in lib.rt_last_error()
+    fr = kernel.driver_frame(0)
+    fr.num_lights = 101
+    assert lib.rt_render_rows(sc.h, C.byref(fr), 4, 4, TAN_HALF, 0, 4, hit.data_ptr(), None, None, None) == -1
+    assert lib.rt_init(99) == -1
+    sc.close()
+
+
+def test_far_ray_origins_outside_the_error_model_still_exact_in_practice():
+    """rt_trace_rays documents a 3x-scene-radius limit on ray origins for the fp32 filter's
+    bound; rays from 10x further still match here (the bound has a ~12x safety factor)."""
+    mesh = scenes.sphere(400)
+    fr = kernel.driver_frame(0)
+    X, Y, Z = O.transform(mesh, kernel.frame_matrix(fr, "obmat"))
+    osc = O.Scene(mesh, X, Y, Z)
+    c = np.array([X[1:].mean(), Y[1:].mean(), Z[1:].mean()])
+    rng = np.random.default_rng(2)
+    d = rng.normal(size=(500, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    S = c + 300.0 * d
+    E = c + rng.uniform(-6, 6, size=(500, 3))
+    sc = kernel.Scene(mesh)
+    sc.transform(kernel.frame_matrix(fr, "obmat"))
+    hit, _, _ = sc.trace_rays(S, E)
+    hit = hit.cpu().numpy()
+    assert sum(int(hit[k] != O.intersect(osc, S[k], E[k])[0]) for k in range(500)) == 0
+    sc.close()
