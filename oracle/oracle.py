@@ -99,6 +99,8 @@ def lib() -> C.CDLL:
         L.orc_place_pixels.restype = None
         L.orc_place_pixels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_num_threads.restype = C.c_int
+        L.orc_trace_rays.restype = None
+        L.orc_trace_rays.argtypes = [C.POINTER(OrcScene), C.c_long, dp, dp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -235,6 +237,18 @@ def intersect(scene: Scene, S, E):
     uv, point, t = np.zeros(2), np.zeros(3), C.c_double(0)
     idx = lib().orc_scene_intersect(C.byref(scene.s), d(S), d(E), d(uv), d(point), C.byref(t))
     return idx, t.value, uv, point
+
+
+def trace_rays(scene: Scene, S, E, nthreads: int = 0):
+    S = np.ascontiguousarray(S, np.float64)
+    E = np.ascontiguousarray(E, np.float64)
+    n = S.shape[0]
+    hit = np.full(n, -1, np.int32)
+    tuv = np.zeros((n, 3))
+    point = np.zeros((n, 3))
+    lib().orc_trace_rays(C.byref(scene.s), n, d(S), d(E), hit.ctypes.data, tuv.ctypes.data,
+                         point.ctypes.data, nthreads)
+    return hit, tuv, point
 
 
 def place_pixels(rgb8: np.ndarray) -> np.ndarray:

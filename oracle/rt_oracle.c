@@ -634,6 +634,29 @@ void orc_place_pixels(const uint8_t* rgb8, int W, int H, uint8_t* screen)
         memcpy(screen + (size_t)(H - y_pix) * W * 3, rgb8 + (size_t)y_pix * W * 3, (size_t)W * 3);
 }
 
+/* n independent rays through orc_scene_intersect (OpenMP over rays): S, E as 3 doubles per
+ * ray; hit[i] = index or -1; tuv (3 per ray) and point (3 per ray) written on a hit. */
+void orc_trace_rays(const OrcScene* sc, long n, const double* S, const double* E,
+                    int32_t* hit, double* tuv, double* point, int nthreads)
+{
+    long i;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 64)
+    for (i = 0; i < n; i++) {
+        double uv[2] = {0, 0}, p[3] = {0, 0, 0}, t = 0;
+        int s = intersect_all_t(sc, S + 3 * i, E + 3 * i, uv, p, &t);
+        hit[i] = s;
+        if (s != -1) {
+            if (tuv) { tuv[3 * i] = t; tuv[3 * i + 1] = uv[0]; tuv[3 * i + 2] = uv[1]; }
+            if (point) { point[3 * i] = p[0]; point[3 * i + 1] = p[1]; point[3 * i + 2] = p[2]; }
+        }
+    }
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

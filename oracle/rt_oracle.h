@@ -86,6 +86,8 @@ long orc_render_rows(const OrcScene* sc, const OrcFrame* f, int W, int H, double
                      int y0, int y1, int ystep, int shade, int nthreads,
                      int32_t* hit, double* tuv, double* argb, uint8_t* rgb8);
 void orc_place_pixels(const uint8_t* rgb8, int W, int H, uint8_t* screen);
+void orc_trace_rays(const OrcScene* sc, long n, const double* S, const double* E,
+                    int32_t* hit, double* tuv, double* point, int nthreads);
 int orc_num_threads(void);
 
 #ifdef __cplusplus
