@@ -50,6 +50,19 @@ def make_mesh(kind: str, tris: int):
     return scenes.sphere(tris)
 
 
+def measured_traffic(workload: str, cfg) -> dict | None:
+    """HBM-side bytes of one closest-hit sweep launch of this workload and kernel configuration,
+    from the committed rocprofv3 counter passes (profiles/traffic.json; FETCH_SIZE and WRITE_SIZE
+    are collected in runs of their own, so they cannot be read live).  None when no pass was
+    recorded for this exact configuration."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            table = json.load(f)
+    except OSError:
+        return None
+    return table.get(f"{workload}/form{cfg[0]}-tile{cfg[1]}-rpl{cfg[2]}")
+
+
 def cpu_baseline(mesh, frame, W, H, budget_s: float = 15.0):
     """CPU oracle (strict fp64 restatement of the reference's formulas, OpenMP over rows) on
     a bounded row sample of the same frame; primary rays only."""
@@ -197,6 +210,7 @@ def main() -> None:
         _lib.load().rt_sweep_config(*[C.byref(c) for c in cfg])
         f_exec = float(cfg[3].value)
         achieved = nominal * f_exec / F_TEST      # flops the hot loop really executes
+        traffic = measured_traffic(args.workload, [c.value for c in cfg]) if world == 1 else None
         res = {
             "metric": "Mrays/s and ray-tri tests/s (% fp32 peak) at 1/2/4/8 MI355X vs host-CPU ref",
             "value": (rays_p + rays_s) / (wall / steps) / 1e6,
@@ -228,7 +242,9 @@ def main() -> None:
                 "frac": achieved / PEAK_FP32_TFLOPS,
                 "avg_launch_ms": sweep_ms_avg, "tests_per_launch": tests_per_launch,
                 "tests_per_s": tests_per_launch / (sweep_ms_avg * 1e-3) if sweep_ms_avg > 0 else 0.0,
-                "flop_per_test": f_exec, "traffic": None,
+                "flop_per_test": f_exec,
+                "traffic": traffic["bytes"] if traffic else None,
+                "traffic_source": traffic["source"] if traffic else None,
                 "flop_per_test_nominal": F_TEST, "achieved_nominal": nominal,
                 "frac_nominal": nominal / PEAK_FP32_TFLOPS,
                 "sweep_kernel": {"form": cfg[0].value, "tile_tris": cfg[1].value, "rays_per_lane": cfg[2].value},
