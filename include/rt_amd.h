@@ -170,10 +170,15 @@ typedef struct rt_profile {
     uint64_t exact_overflow;    /* rays that fell back to the full fp64 sweep */
     uint64_t rays_live;         /* generic-ray launches: rays in use (unused slots excluded) */
 } rt_profile;
-/* Compile-time shape of the sweep kernel: formulation (0 = textbook Moller-Trumbore order,
- * 1 = shared cross product + stored normal), triangles per LDS tile, rays per lane, and the
+/* Compile-time shape of the sweep kernel for rays in general position (rt_trace_rays,
+ * rt_occluded): formulation (2 = moment form), triangles per LDS tile, rays per lane, and the
  * fp32 flops the hot loop executes per ray-triangle pair (FMA = 2). */
 int rt_sweep_config(int* form, int* tile_tris, int* rays_per_lane, int* flop_per_pair);
+/* Same for the two sweeps of the pixel loop (rt_trace_primary, rt_render_rows): the
+ * pixel-grid sweep of the primary rays and the per-light any-hit sweep of the shadow rays. */
+int rt_apex_sweep_config(int* tile_tris, int* primary_pixels_per_lane,
+                         double* primary_flop_per_pair, int* shadow_rays_per_lane,
+                         double* shadow_flop_per_pair);
 int rt_profile_enable(int on);     /* wraps sweep launches in HIP events and reads the device
                                       counters back (adds a sync per launch); the ray and
                                       candidate counts above are only collected while on */

@@ -97,6 +97,8 @@ SIGNATURES = {
     "rt_place_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rt_band": (C.c_int, [C.c_int, C.c_int, C.c_int, c_int_p, c_int_p]),
     "rt_sweep_config": (C.c_int, [c_int_p] * 4),
+    "rt_apex_sweep_config": (C.c_int, [c_int_p, c_int_p, C.POINTER(C.c_double), c_int_p,
+                                       C.POINTER(C.c_double)]),
     "rt_profile_enable": (C.c_int, [C.c_int]),
     "rt_profile_reset": (C.c_int, []),
     "rt_profile_get": (C.c_int, [C.POINTER(RtProfile)]),

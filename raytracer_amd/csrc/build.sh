@@ -11,14 +11,14 @@ FLAGS=(-O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -I"$root/inc
 objs=()
 bdir="${RT_AMD_BUILD_DIR:-$here/build}"
 mkdir -p "$bdir"
-for src in rt_sweep.hip rt_exact.hip rt_transform.hip rt_shade.hip rt_api.hip rt_host.cpp rt_obj.cpp; do
+for src in rt_sweep.hip rt_sweep_apex.hip rt_exact.hip rt_transform.hip rt_shade.hip rt_api.hip rt_host.cpp rt_obj.cpp; do
   obj="$bdir/${src%.*}.o"
-  if [ ! -f "$obj" ] || [ "$here/$src" -nt "$obj" ] || [ "$here/rt_internal.h" -nt "$obj" ] || [ "$root/include/rt_amd.h" -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$here/$src" -nt "$obj" ] || [ "$here/rt_internal.h" -nt "$obj" ] || [ "$here/rt_sweep_common.h" -nt "$obj" ] || [ "$root/include/rt_amd.h" -nt "$obj" ]; then
     echo "hipcc $src"
     extra=()
     # The sweep must stay scalar fp32: SLP-packing it into v_pk_* costs shuffles and doubles the
     # issue time of each packed instruction on gfx950, a net loss for this loop.
-    [ "$src" = rt_sweep.hip ] && extra=(-fno-slp-vectorize)
+    case "$src" in rt_sweep*.hip) extra=(-fno-slp-vectorize --save-temps=obj) ;; esac
     "$HIPCC" "${FLAGS[@]}" "${extra[@]}" ${EXTRA_FLAGS:-} -c "$here/$src" -o "$obj"
   fi
   objs+=("$obj")

@@ -83,10 +83,22 @@ extern "C" int rt_set_stream(void* hip_stream)
 
 extern "C" int rt_sweep_config(int* form, int* tile_tris, int* rays_per_lane, int* flop_per_pair)
 {
-    if (form) *form = RT_SWEEP_FORM;
+    if (form) *form = 2;        // moment form
     if (tile_tris) *tile_tris = RT_TILE;
     if (rays_per_lane) *rays_per_lane = RT_RPL;
     if (flop_per_pair) *flop_per_pair = RT_FLOP_PER_PAIR;
+    return RT_OK;
+}
+
+extern "C" int rt_apex_sweep_config(int* tile_tris, int* primary_pixels_per_lane,
+                                    double* primary_flop_per_pair, int* shadow_rays_per_lane,
+                                    double* shadow_flop_per_pair)
+{
+    if (tile_tris) *tile_tris = RT_TILE;
+    if (primary_pixels_per_lane) *primary_pixels_per_lane = RT_RASTER_RPL;
+    if (primary_flop_per_pair) *primary_flop_per_pair = RT_RASTER_FLOP_PER_PAIR;
+    if (shadow_rays_per_lane) *shadow_rays_per_lane = RT_APEX_RPL;
+    if (shadow_flop_per_pair) *shadow_flop_per_pair = RT_APEX_FLOP_PER_PAIR;
     return RT_OK;
 }
 
@@ -145,7 +157,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
     if (!sc) return RT_OK;
     DevBuf* bufs[] = {&sc->ox, &sc->oy, &sc->oz, &sc->ex, &sc->ey, &sc->ez, &sc->nx, &sc->ny, &sc->nz,
                       &sc->tu, &sc->tv, &sc->iA, &sc->iB, &sc->iC, &sc->iAn, &sc->iBn, &sc->iCn,
-                      &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes,
+                      &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex,
                       &sc->scratch_max, &sc->mat_dev, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
                       &sc->ws_occ, &sc->ws_act0, &sc->ws_act1};
@@ -253,6 +265,7 @@ extern "C" int rt_scene_set_triangles(rt_scene* sc, int num_tris, const int* A, 
     if (sc->num_tris_padded == 0) sc->num_tris_padded = RT_TILE;
     const size_t pb = sizeof(float4) * (size_t)sc->num_tris_padded;
     RT_TRY(sc->planes.reserve(pb * RT_PLANES));
+    RT_TRY(sc->planes_apex.reserve(pb * RT_APEX_PLANES));
     RT_TRY(sc->scratch_max.reserve(16));
     sc->transformed = false;
     return RT_OK;
@@ -396,10 +409,17 @@ static int transform_into(rt_scene* sc, const double m[4][4], bool bake)
             if (rc) break;
             sc->transformed = true;
         }
+        float radius = 0;
+        if (!bake && hipMemcpyAsync(&radius, sc->scratch_max.p, sizeof radius, hipMemcpyDeviceToHost,
+                                    st) != hipSuccess) {
+            rc = RT_E_HIP;
+            break;
+        }
         if (hipStreamSynchronize(st) != hipSuccess) {
             rt_set_error("transform: kernel failed: %s", hipGetErrorString(hipGetLastError()));
             rc = RT_E_HIP;
         }
+        if (!bake) sc->radius = (double)radius;
     } while (0);
     return rc;
 }
@@ -503,17 +523,24 @@ extern "C" int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int
     RT_TRY(workspaces(sc, npix));
     RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
 
+    // planes for rays from the eye; the constant z of the pixel-grid directions is folded in
+    const double ez = (double)(W / 2) / tan_half;       // driver.c:133
+    const double eye[3] = {0, 0, 0};                    // driver.c:121-123
+    const double hw = 0.5 * W + 1, hh = 0.5 * H + 1;
+    RT_TRY(rt_launch_pack_apex(sc, eye, ez, sqrt(hw * hw + hh * hh + ez * ez), st));
+
     SweepArgs a{};
-    a.planes = sc->planes.as<float4>(); a.plane_stride = sc->num_tris_padded;
+    a.planes = sc->planes_apex.as<float4>(); a.plane_stride = sc->num_tris_padded;
     a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
     a.W = W; a.H = H; a.y0 = y0; a.y1 = y1;
-    a.ez = (double)(W / 2) / tan_half;
+    a.ez = ez;
     a.cnt = sc->ws_cnt.as<int32_t>(); a.list = sc->ws_list.as<int32_t>();
     a.tests = nullptr;
     a.tri_begin = 0; a.tri_end = sc->num_tris_padded;
-    const int tiles_x = (W + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (y1 - y0 + RT_TILE_H - 1) / RT_TILE_H;
-    const uint64_t tests = (uint64_t)tiles_x * tiles_y * RT_RAYS_PER_WG * (uint64_t)sc->num_tris_padded;
-    RT_TRY(timed_sweep([&] { return rt_launch_sweep_primary(a, st); }, false, tests, nullptr));
+    const int tiles_x = (W + RT_RASTER_TILE_W - 1) / RT_RASTER_TILE_W;
+    const int tiles_y = (y1 - y0 + RT_TILE_H - 1) / RT_TILE_H;
+    const uint64_t tests = (uint64_t)tiles_x * tiles_y * (RT_WG * RT_RASTER_RPL) * (uint64_t)sc->num_tris_padded;
+    RT_TRY(timed_sweep([&] { return rt_launch_sweep_raster(a, st); }, false, tests, nullptr));
     g.prof.rays_primary += npix;
 
     const ExactScene es = exact_of(sc);
@@ -527,19 +554,81 @@ extern "C" int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int
     return RT_OK;
 }
 
-static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E, bool anyhit,
-                           int tiledW, int y0, int y1, int32_t* hit, double* tuv, double* point,
-                           uint8_t* occ)
+// Any-hit sweep in triangle ranges of doubling length; the survivors are compacted between
+// ranges, so a ray's cost becomes ~ the index of its first certain occluder, not the mesh
+// size.  `a` describes the first range's launch (all n rays); later ranges run indexed over
+// the survivor list.  launch(a) starts one range.
+template <class Launch>
+static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, Launch&& launch)
+{
+    hipStream_t st = rt_g().stream;
+    const int np = sc->num_tris_padded;
+    RT_TRY(sc->ws_act0.reserve(sizeof(int32_t) * (size_t)n));
+    RT_TRY(sc->ws_act1.reserve(sizeof(int32_t) * (size_t)n));
+    int32_t* act[2] = {sc->ws_act0.as<int32_t>(), sc->ws_act1.as<int32_t>()};
+    int* live_count = sc->ws_counters.as<int>() + 8;        // counters[8]
+    int first = np / 64;
+    first = ((first + RT_TILE - 1) / RT_TILE) * RT_TILE;
+    if (first < 16 * RT_TILE) first = 16 * RT_TILE;
+    int begin = 0, len = first, live = n, cur = 0;
+    bool indexed = false;
+    while (begin < np && live > 0) {
+        int end = begin + len;
+        if (end > np || np - end < len / 2) end = np;
+        a.tri_begin = begin; a.tri_end = end;
+        a.resume = begin > 0;
+        a.active = indexed ? act[cur] : nullptr;
+        a.n_rays = indexed ? live : n;
+        RT_TRY(timed_sweep([&] { return launch(a); }, true, 0, a.tests));
+        if (getenv("RT_AMD_TRACE_PASSES"))
+            fprintf(stderr, "rt_amd: any-hit range [%d,%d) over %d rays\n", begin, end,
+                    indexed ? live : n);
+        begin = end;
+        if (begin >= np) break;
+        // compact the survivors (first time from the full range, then from the last list)
+        RT_HIP(hipMemsetAsync(live_count, 0, sizeof(int), st));
+        RT_TRY(rt_launch_compact(a.cnt, indexed ? act[cur] : nullptr, indexed ? live : n,
+                                 act[cur ^ 1], live_count, st));
+        RT_HIP(hipMemcpyAsync(&live, live_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        RT_HIP(hipStreamSynchronize(st));
+        cur ^= 1;
+        indexed = true;
+        len *= 2;
+    }
+    return RT_OK;
+}
+
+// fp64 confirmation of the candidate lists of n rays + the overflow fallback + statistics
+static int resolve_rays(rt_scene* sc, int n, const double* S, const double* E, bool anyhit,
+                        int32_t* hit, double* tuv, double* point, uint8_t* occ)
 {
     RtGlobal& g = rt_g();
-    hipStream_t st = g.stream;
+    const ExactScene es = exact_of(sc);
+    int* counters = sc->ws_counters.as<int>();
+    RT_TRY(rt_launch_resolve_rays(es, n, S, E, sc->ws_cnt.as<int32_t>(), sc->ws_list.as<int32_t>(),
+                                  anyhit, hit, tuv, point, occ, sc->ws_ovf.as<int32_t>(), counters,
+                                  g.stream));
+    RT_TRY(rt_launch_overflow_rays(es, S, E, sc->ws_ovf.as<int32_t>(), counters, anyhit, hit, tuv,
+                                   point, occ, g.stream));
+    const uint64_t before = g.prof.rays_live;
+    RT_TRY(fetch_counters(sc, false));
+    if (anyhit) g.prof.rays_shadow += g.prof.rays_live - before;
+    else g.prof.rays_primary += g.prof.rays_live - before;
+    return RT_OK;
+}
+
+// Rays in general position (rt_sweep.hip).
+static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E, bool anyhit,
+                           int32_t* hit, double* tuv, double* point, uint8_t* occ)
+{
+    hipStream_t st = rt_g().stream;
     if (n == 0) return RT_OK;
     RT_TRY(workspaces(sc, (size_t)n));
     RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
     SweepArgs a{};
     a.planes = sc->planes.as<float4>(); a.plane_stride = sc->num_tris_padded;
     a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
-    a.W = tiledW; a.y0 = y0; a.y1 = y1; a.H = 0;
+    a.scene_radius = sc->radius;
     a.n_rays = n; a.S = S; a.E = E;
     a.cnt = sc->ws_cnt.as<int32_t>(); a.list = sc->ws_list.as<int32_t>();
     a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
@@ -550,54 +639,34 @@ static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E
         RT_TRY(timed_sweep([&] { return rt_launch_sweep_rays(a, false, st); }, false,
                            wgs * RT_RAYS_PER_WG * (uint64_t)np, a.tests));
     } else {
-        // Any-hit: triangle ranges of doubling length, survivors compacted between ranges.
-        // A ray's cost becomes ~ the index of its first certain occluder, not the mesh size.
-        RT_TRY(sc->ws_act0.reserve(sizeof(int32_t) * (size_t)n));
-        RT_TRY(sc->ws_act1.reserve(sizeof(int32_t) * (size_t)n));
-        int32_t* act[2] = {sc->ws_act0.as<int32_t>(), sc->ws_act1.as<int32_t>()};
-        int* live_count = sc->ws_counters.as<int>() + 8;        // counters[8]
-        int first = np / 64;
-        first = ((first + RT_TILE - 1) / RT_TILE) * RT_TILE;
-        if (first < 16 * RT_TILE) first = 16 * RT_TILE;
-        int begin = 0, len = first, live = n, cur = 0;
-        bool indexed = false;
-        while (begin < np && live > 0) {
-            int end = begin + len;
-            if (end > np || np - end < len / 2) end = np;
-            a.tri_begin = begin; a.tri_end = end;
-            a.resume = begin > 0;
-            a.active = indexed ? act[cur] : nullptr;
-            a.n_rays = indexed ? live : n;
-            RT_TRY(timed_sweep([&] { return rt_launch_sweep_rays(a, true, st); }, true, 0, a.tests));
-            if (getenv("RT_AMD_TRACE_PASSES"))
-                fprintf(stderr, "rt_amd: any-hit range [%d,%d) over %d rays\n", begin, end,
-                        indexed ? live : n);
-            begin = end;
-            if (begin >= np) break;
-            // compact the survivors (first time from the full range, then from the last list)
-            RT_HIP(hipMemsetAsync(live_count, 0, sizeof(int), st));
-            RT_TRY(rt_launch_compact(a.cnt, indexed ? act[cur] : nullptr, indexed ? live : n,
-                                     act[cur ^ 1], live_count, st));
-            RT_HIP(hipMemcpyAsync(&live, live_count, sizeof(int), hipMemcpyDeviceToHost, st));
-            RT_HIP(hipStreamSynchronize(st));
-            cur ^= 1;
-            indexed = true;
-            len *= 2;
-        }
+        RT_TRY(anyhit_ranges(sc, a, n, [&](const SweepArgs& r) { return rt_launch_sweep_rays(r, true, st); }));
     }
-    const ExactScene es = exact_of(sc);
-    int* counters = sc->ws_counters.as<int>();
-    RT_TRY(rt_launch_resolve_rays(es, n, S, E, a.cnt, a.list, anyhit, hit, tuv, point, occ,
-                                  sc->ws_ovf.as<int32_t>(), counters, st));
-    RT_TRY(rt_launch_overflow_rays(es, S, E, sc->ws_ovf.as<int32_t>(), counters, anyhit, hit, tuv,
-                                   point, occ, st));
-    {
-        const uint64_t before = g.prof.rays_live;
-        RT_TRY(fetch_counters(sc, false));
-        if (anyhit) g.prof.rays_shadow += g.prof.rays_live - before;
-        else g.prof.rays_primary += g.prof.rays_live - before;
+    return resolve_rays(sc, n, S, E, anyhit, hit, tuv, point, occ);
+}
+
+// Shadow rays of the pixel loop: [light][pixel] rays that end at their light (k_shadow_setup).
+// One apex sweep per light over planes packed relative to that light (rt_sweep_apex.hip).
+static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int y0, int y1,
+                             const double* S, const double* E, uint8_t* occ)
+{
+    hipStream_t st = rt_g().stream;
+    const size_t npix = (size_t)W * (y1 - y0);
+    const int L = f->num_lights;
+    RT_TRY(workspaces(sc, npix * (size_t)L));
+    RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
+    for (int l = 0; l < L; ++l) {
+        RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l], 1.0, 1.0, st));
+        SweepArgs a{};
+        a.planes = sc->planes_apex.as<float4>(); a.plane_stride = sc->num_tris_padded;
+        a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
+        a.W = W; a.y0 = y0; a.y1 = y1; a.H = 0;
+        a.S = S + 3 * npix * (size_t)l; a.E = E + 3 * npix * (size_t)l;
+        a.cnt = sc->ws_cnt.as<int32_t>() + npix * (size_t)l;
+        a.list = sc->ws_list.as<int32_t>() + npix * (size_t)l * RT_LIST_K;
+        a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
+        RT_TRY(anyhit_ranges(sc, a, (int)npix, [&](const SweepArgs& r) { return rt_launch_sweep_apex(r, st); }));
     }
-    return RT_OK;
+    return resolve_rays(sc, (int)(npix * (size_t)L), S, E, true, nullptr, nullptr, nullptr, occ);
 }
 
 extern "C" int rt_trace_rays(rt_scene* sc, int n, const double* S, const double* E, int32_t* hit,
@@ -606,7 +675,7 @@ extern "C" int rt_trace_rays(rt_scene* sc, int n, const double* S, const double*
     RT_TRY(require_ready(sc));
     RT_ARG(n >= 0, "negative ray count");
     RT_ARG(n == 0 || (S && E && hit), "null pointer");
-    RT_TRY(trace_rays_impl(sc, n, S, E, false, 0, 0, 0, hit, tuv, point, nullptr));
+    RT_TRY(trace_rays_impl(sc, n, S, E, false, hit, tuv, point, nullptr));
     RT_HIP(hipStreamSynchronize(rt_g().stream));
     return RT_OK;
 }
@@ -616,7 +685,7 @@ extern "C" int rt_occluded(rt_scene* sc, int n, const double* S, const double* E
     RT_TRY(require_ready(sc));
     RT_ARG(n >= 0, "negative ray count");
     RT_ARG(n == 0 || (S && E && occ), "null pointer");
-    RT_TRY(trace_rays_impl(sc, n, S, E, true, 0, 0, 0, nullptr, nullptr, nullptr, occ));
+    RT_TRY(trace_rays_impl(sc, n, S, E, true, nullptr, nullptr, nullptr, occ));
     RT_HIP(hipStreamSynchronize(rt_g().stream));
     return RT_OK;
 }
@@ -678,8 +747,7 @@ extern "C" int rt_render_rows(rt_scene* sc, const rt_frame* f, int W, int H, dou
         a.shS = sc->ws_shS.as<double>(); a.shE = sc->ws_shE.as<double>();
         a.occ = sc->ws_occ.as<uint8_t>();
         RT_TRY(rt_launch_shadow_setup(a, st));
-        RT_TRY(trace_rays_impl(sc, (int)nsh, a.shS, a.shE, true, W, y0, y1, nullptr, nullptr,
-                               nullptr, sc->ws_occ.as<uint8_t>()));
+        RT_TRY(trace_shadow_rays(sc, f, W, y0, y1, a.shS, a.shE, sc->ws_occ.as<uint8_t>()));
     }
     RT_TRY(rt_launch_shade_final(a, st));
     RT_HIP(hipStreamSynchronize(st));

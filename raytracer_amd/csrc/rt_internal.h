@@ -34,32 +34,43 @@ void rt_set_error(const char* fmt, ...);
 
 // ---------------------------------------------------------------- tunables
 constexpr int RT_WG = 256;          // threads per workgroup of every kernel here (4 waves)
-#ifndef RT_SWEEP_FORM
-#define RT_SWEEP_FORM 2     // evaluation order of the pair test, see rt_sweep.hip (0, 1 or 2)
-#endif
 #ifndef RT_TILE_TRIS
 #define RT_TILE_TRIS 128
 #endif
 #ifndef RT_RAYS_PER_LANE
-#define RT_RAYS_PER_LANE (RT_SWEEP_FORM == 2 ? 4 : 2)
-#endif
-#ifndef RT_MERGED_BRANCH
-#define RT_MERGED_BRANCH 1  // form 2: one rare-path branch per triangle (all rays of a lane) instead of per pair
+#define RT_RAYS_PER_LANE 4  // rays per lane of the general-position sweep
 #endif
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 1      // __launch_bounds__ waves per SIMD the sweep's register allocation must allow
+#define RT_MIN_WAVES 1      // __launch_bounds__ waves per SIMD the sweeps' register allocation must allow
 #endif
-// float4 planes per triangle in the sweep buffer and in each LDS tile
-constexpr int RT_PLANES = RT_SWEEP_FORM == 0 ? 3 : (RT_SWEEP_FORM == 1 ? 4 : 5);
-// fp32 flops the hot loop executes per pair before the lazily evaluated parts (FMA = 2):
-//   form 0: 5 add + 12 mul + 12 fma = 41;  form 1: 3 add + 6 mul + 9 fma = 27;  form 2: 3 mul + 9 fma = 21
-constexpr int RT_FLOP_PER_PAIR = RT_SWEEP_FORM == 0 ? 41 : (RT_SWEEP_FORM == 1 ? 27 : 21);
+// general-position sweep (rt_sweep.hip, moment form): float4 planes per triangle in the sweep
+// buffer and in each LDS tile, and the fp32 flops its hot loop executes per pair before the
+// lazily evaluated parts (3 mul + 9 FMA)
+constexpr int RT_PLANES = 5;
+constexpr int RT_FLOP_PER_PAIR = 21;
 constexpr int RT_TILE = RT_TILE_TRIS;      // triangles per LDS tile of the sweep
 constexpr int RT_RPL = RT_RAYS_PER_LANE;   // rays per lane in the sweep
 constexpr int RT_LIST_K = 16;       // candidate slots per ray handed to the fp64 confirmation
 constexpr int RT_TILE_W = 16 * RT_RPL;   // pixel tile of one workgroup: 2x2 waves of (8*RPL)x8
 constexpr int RT_TILE_H = 16;
 constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
+
+// Sweeps of rays through a common point (rt_sweep_apex.hip): the eye for primary rays, a
+// light for its shadow rays.  4 float4 planes per triangle, packed per apex by k_pack_apex.
+#ifndef RT_RASTER_RPL
+#define RT_RASTER_RPL 8     // pixels per lane of the primary (pixel-grid) sweep
+#endif
+#ifndef RT_APEX_RPL
+#define RT_APEX_RPL 4       // rays per lane of the any-hit apex sweep
+#endif
+constexpr int RT_APEX_PLANES = 4;
+constexpr int RT_RASTER_TILE_W = 16 * RT_RASTER_RPL;   // workgroup = 2x2 waves of (8*RPL) x 8 pixels
+constexpr int RT_APEX_TILE_W = 16 * RT_APEX_RPL;
+// fp32 flops per pair in the hot loops (FMA = 2).  Pixel-grid sweep, per lane and triangle:
+// 2 row terms + 2 FMA per pixel for the two plane distances + 1 FMA per pixel for the
+// slab product.  Apex sweep: two 3-term dot products (1 mul + 2 FMA each) + 1 FMA.
+constexpr double RT_RASTER_FLOP_PER_PAIR = (2.0 * 2 + RT_RASTER_RPL * 3 * 2.0) / RT_RASTER_RPL;
+constexpr double RT_APEX_FLOP_PER_PAIR = 12.0;
 
 // per-ray candidate counter written by the sweep: low bits = candidates pushed, plus
 constexpr int RT_CNT_OCCLUDED = 0x40000000;   // any-hit: a certain hit was found
@@ -81,6 +92,7 @@ struct rt_scene {
     int num_v = 0, num_vn = 0, num_vt = 0, num_tris = 0, num_mats = 0, num_tex = 0;
     int num_tris_padded = 0;
     bool transformed = false;
+    double radius = 0;          // largest |coordinate| of the eye-space vertices (host copy)
 
     // object-space master + eye-space working copy, fp64 SoA, 1-indexed (slot 0 carried along)
     DevBuf ox, oy, oz, ex, ey, ez;
@@ -95,6 +107,8 @@ struct rt_scene {
     // fp32 sweep buffer: RT_PLANES float4 planes of num_tris_padded entries each, back to back
     // (contents per formulation: k_pack in rt_transform.hip)
     DevBuf planes;
+    // same for the apex sweeps: RT_APEX_PLANES planes, repacked for the eye and for each light
+    DevBuf planes_apex;
     DevBuf scratch_max;         // 1 float: max |coordinate| of the eye-space vertices
     DevBuf mat_dev;             // the 4x4 of the current transform
 
@@ -139,6 +153,9 @@ int rt_ensure_init();
 int rt_launch_transform(const double* m16, const double* x, const double* y, const double* z,
                         double* X, double* Y, double* Z, int n, unsigned* max_bits, hipStream_t st);
 int rt_launch_pack(rt_scene* sc, hipStream_t st);
+// apex planes for rays through `apex`; zs is folded into the z components (the constant z of
+// pixel-grid directions, 1 otherwise); dmax bounds |D| of every ray of the sweep
+int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, hipStream_t st);
 
 // rt_sweep.hip
 struct SweepArgs {
@@ -152,6 +169,7 @@ struct SweepArgs {
     int n_rays;
     const double *S, *E;    // 3 doubles per ray
     const int32_t* active;  // indexed mode: n_rays ray numbers to work on (else nullptr)
+    double scene_radius;    // largest |coordinate| of the eye-space vertices (general-position sweep)
     // triangle range of this launch, tile-aligned; resume = pick up cnt[] left by an earlier range
     int tri_begin, tri_end;
     int resume;
@@ -160,8 +178,10 @@ struct SweepArgs {
     int32_t* list;          // RT_LIST_K candidate triangle indices per ray
     unsigned long long* tests;   // pairs evaluated, accumulated per workgroup (may be nullptr)
 };
-int rt_launch_sweep_primary(const SweepArgs& a, hipStream_t st);
 int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st);
+// rt_sweep_apex.hip: a.planes = apex planes (RT_APEX_PLANES of them)
+int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st);   // primary rays, closest hit
+int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st);     // any-hit; tiled (W > 0) or indexed
 int rt_launch_compact(const int32_t* cnt, const int32_t* in, int n, int32_t* out, int* out_count,
                       hipStream_t st);
 

@@ -5,10 +5,10 @@
 // fully coalesced (24 B in, 24 B out per point).  It is compiled without FMA contraction so
 // the result equals the host twin M3d_mat_mult_points (M3d_matrix_tools.c:184-208) bit for bit.
 //
-// k_pack derives, per triangle, what the sweep consumes -- v0 = A, e1 = B-A, e2 = C-A and,
-// depending on the formulation, nn = e2 x e1, g = e2 x v0, h = e1 x v0, k = v0.nn (everything
-// formed in fp64, then rounded once to fp32) -- plus two rounding bounds that make the fp32
-// test a conservative filter (see rt_sweep.hip):
+// k_pack derives, per triangle, what the general-position sweep consumes -- with v0 = A,
+// e1 = B-A, e2 = C-A: nn = e2 x e1, g = e2 x v0, h = e1 x v0, k = v0.nn (everything formed in
+// fp64, then rounded once to fp32) -- plus two rounding bounds that make the fp32 test a
+// conservative filter (see rt_sweep.hip):
 //     eu bounds |error of U*, V*, det-U-V| for a unit-length ray direction,
 //     et bounds |error of T|,
 // both proportional to 2^-20 * (4 * largest |coordinate| in eye space) * edge lengths.
@@ -69,17 +69,6 @@ k_pack(const double* __restrict__ x, const double* __restrict__ y, const double*
     const float et = (float)(scale * l1 * l2);
     // nn = e2 x e1, so that det = e1.(D x e2) = D.nn
     const double nx = e2y * e1z - e2z * e1y, ny = e2z * e1x - e2x * e1z, nz = e2x * e1y - e2y * e1x;
-#if RT_SWEEP_FORM == 0
-    *p[0] = make_float4((float)ax, (float)ay, (float)az, eu);
-    *p[1] = make_float4((float)e1x, (float)e1y, (float)e1z, et);
-    *p[2] = make_float4((float)e2x, (float)e2y, (float)e2z, 0.0f);
-    (void)eu2; (void)nx; (void)ny; (void)nz;
-#elif RT_SWEEP_FORM == 1
-    *p[0] = make_float4((float)ax, (float)ay, (float)az, eu);
-    *p[1] = make_float4((float)e2x, (float)e2y, (float)e2z, eu2);
-    *p[2] = make_float4((float)nx, (float)ny, (float)nz, 0.0f);
-    *p[3] = make_float4((float)e1x, (float)e1y, (float)e1z, et);
-#else
     // moment form: g = e2 x v0, h = e1 x v0, k = v0.nn -- all formed in fp64, rounded once
     const double gx = e2y * az - e2z * ay, gy = e2z * ax - e2x * az, gz = e2x * ay - e2y * ax;
     const double hx = e1y * az - e1z * ay, hy = e1z * ax - e1x * az, hz = e1x * ay - e1y * ax;
@@ -89,10 +78,102 @@ k_pack(const double* __restrict__ x, const double* __restrict__ y, const double*
     *p[2] = make_float4((float)e2x, (float)e2y, (float)e2z, et);
     *p[3] = make_float4((float)e1x, (float)e1y, (float)e1z, (float)k);
     *p[4] = make_float4((float)hx, (float)hy, (float)hz, 0.0f);
-#endif
+}
+
+// Planes for sweeps of rays that all pass through one point P (the apex): the eye for primary
+// rays, a light for its shadow rays.  With a_i = v_i - P, e1 = a1 - a0, e2 = a2 - a0 and any
+// direction D of such a ray, the determinants of triangle_intersection.cu:59-94 reduce to dot
+// products with four per-triangle vectors (the tvec x D term of the general case vanishes):
+//     U  = D.p,   p  = a0 x e2        (u  = U / det)
+//     W' = D.q,   q  = e2 x a1        (W' = det - U, so u <= 1  <=>  W'/det >= 0)
+//     V  = D.h,   h  = e1 x a0        (v  = V / det)
+//     det = D.nn, nn = e2 x e1,  and the ray parameter from P is k / det with k = a0.nn.
+// Stored per triangle (z components multiplied by zs, see the launcher):
+//     plane 0 = (p, c)   plane 1 = (q, m)   plane 2 = (h, k)   plane 3 = (nn, en)
+// Rounding bounds, with delta = 2^-20 * dmax * rho * l  (rho = distance of the farthest vertex
+// from P, l = longer edge; the true bound on the fp32 error of U, W', V is about 5 * 2^-24 of
+// that product):
+//     c  = delta * (dmax*|nn| + delta): a pair inside the u slab has U, W' of det's sign and
+//          |U| + |W'| = |det|, hence computed U~ * W~' >= -c.  The sweep's first test.
+//     m  = 32 * delta: margin of the full inside test (per unit of |det|).
+//     en = 2^-20 * dmax * |nn|: bound on the error of det.
+// A triangle with an exactly zero normal (repeated or proportional vertices) has a zero
+// determinant in the reference for every ray and can never be hit: it is stored as a null
+// entry (c = -1).  A nearly degenerate one gets m = +inf, which sends every pair inside its
+// slab to the exact pass.
+__global__ void __launch_bounds__(RT_WG)
+k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+            const int* __restrict__ iA, const int* __restrict__ iB, const int* __restrict__ iC,
+            int num_tris, int num_tris_padded, const unsigned* __restrict__ max_bits,
+            double px, double py, double pz, double zs, double dmax, float4* __restrict__ planes)
+{
+    const int i = blockIdx.x * RT_WG + threadIdx.x;
+    if (i >= num_tris_padded) return;
+    float4* p[RT_APEX_PLANES];
+#pragma unroll
+    for (int k = 0; k < RT_APEX_PLANES; ++k) p[k] = planes + (long)k * num_tris_padded + i;
+    const float4 null_entry = make_float4(0, 0, 0, -1.0f);
+    bool null_tri = i >= num_tris;
+    double a0x = 0, a0y = 0, a0z = 0, a1x = 0, a1y = 0, a1z = 0, a2x = 0, a2y = 0, a2z = 0;
+    if (!null_tri) {
+        const int a = iA[i], b = iB[i], c = iC[i];
+        a0x = x[a] - px; a0y = y[a] - py; a0z = z[a] - pz;
+        a1x = x[b] - px; a1y = y[b] - py; a1z = z[b] - pz;
+        a2x = x[c] - px; a2y = y[c] - py; a2z = z[c] - pz;
+    }
+    const double e1x = a1x - a0x, e1y = a1y - a0y, e1z = a1z - a0z;
+    const double e2x = a2x - a0x, e2y = a2y - a0y, e2z = a2z - a0z;
+    const double nx = e2y * e1z - e2z * e1y, ny = e2z * e1x - e2x * e1z, nz = e2x * e1y - e2y * e1x;
+    const double l1 = sqrt(e1x * e1x + e1y * e1y + e1z * e1z);
+    const double l2 = sqrt(e2x * e2x + e2y * e2y + e2z * e2z);
+    const double nn = sqrt(nx * nx + ny * ny + nz * nz);
+    if (!(nn > 0.0) || !(l1 > 0.0) || !(l2 > 0.0)) null_tri = true;      // also catches NaN
+    if (null_tri) {
+#pragma unroll
+        for (int k = 0; k < RT_APEX_PLANES; ++k) *p[k] = null_entry;
+        return;
+    }
+    // p = a0 x e2, q = e2 x a1, h = e1 x a0, k = a0.nn -- formed in fp64, rounded once
+    const double qx_ = e2y * a1z - e2z * a1y, qy_ = e2z * a1x - e2x * a1z, qz_ = e2x * a1y - e2y * a1x;
+    const double ux = a0y * e2z - a0z * e2y, uy = a0z * e2x - a0x * e2z, uz = a0x * e2y - a0y * e2x;
+    const double hx = e1y * a0z - e1z * a0y, hy = e1z * a0x - e1x * a0z, hz = e1x * a0y - e1y * a0x;
+    const double k = a0x * nx + a0y * ny + a0z * nz;
+    const double r0 = sqrt(a0x * a0x + a0y * a0y + a0z * a0z);
+    const double r1 = sqrt(a1x * a1x + a1y * a1y + a1z * a1z);
+    const double r2 = sqrt(a2x * a2x + a2y * a2y + a2z * a2z);
+    const double u20 = 9.5367431640625e-07;      // 2^-20
+    // the floor keeps the bound above the reference's own fp64 rounding for a triangle at P
+    const double big = (double)__uint_as_float(*max_bits) + fabs(px) + fabs(py) + fabs(pz);
+    const double rho = fmax(r0, fmax(r1, r2)) + u20 * big;
+    const double delta = u20 * dmax * rho * fmax(l1, l2);
+    double c = delta * (dmax * nn + delta) * 1.001;
+    if (c < 1.2e-38) c = 1.2e-38;
+    double m = 32.0 * delta;
+    if (nn <= 9.3132257461547852e-10 * l1 * l2) m = (double)__builtin_huge_valf();     // 2^-30
+    const double en = u20 * dmax * nn;
+    *p[0] = make_float4((float)ux, (float)uy, (float)(zs * uz), (float)c * 1.0000002f);
+    *p[1] = make_float4((float)qx_, (float)qy_, (float)(zs * qz_), (float)m);
+    *p[2] = make_float4((float)hx, (float)hy, (float)(zs * hz), (float)k);
+    *p[3] = make_float4((float)nx, (float)ny, (float)(zs * nz), (float)en * 1.0000002f);
 }
 
 }  // namespace
+
+int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, hipStream_t st)
+{
+    const int np = sc->num_tris_padded;
+    hipLaunchKernelGGL(k_pack_apex, dim3((np + RT_WG - 1) / RT_WG), dim3(RT_WG), 0, st,
+                       sc->ex.as<double>(), sc->ey.as<double>(), sc->ez.as<double>(),
+                       sc->iA.as<int>(), sc->iB.as<int>(), sc->iC.as<int>(), sc->num_tris, np,
+                       sc->scratch_max.as<unsigned>(), apex[0], apex[1], apex[2], zs, dmax,
+                       sc->planes_apex.as<float4>());
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        rt_set_error("apex pack launch failed: %s", hipGetErrorString(e));
+        return RT_E_HIP;
+    }
+    return RT_OK;
+}
 
 int rt_launch_transform(const double* m16, const double* x, const double* y, const double* z,
                         double* X, double* Y, double* Z, int n, unsigned* max_bits, hipStream_t st)
