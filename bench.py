@@ -50,7 +50,7 @@ def make_mesh(kind: str, tris: int):
     return scenes.sphere(tris)
 
 
-def measured_traffic(workload: str, cfg) -> dict | None:
+def measured_traffic(workload: str, cfg: str) -> dict | None:
     """HBM-side bytes of one closest-hit sweep launch of this workload and kernel configuration,
     from the committed rocprofv3 counter passes (profiles/traffic.json; FETCH_SIZE and WRITE_SIZE
     are collected in runs of their own, so they cannot be read live).  None when no pass was
@@ -60,7 +60,7 @@ def measured_traffic(workload: str, cfg) -> dict | None:
             table = json.load(f)
     except OSError:
         return None
-    return table.get(f"{workload}/form{cfg[0]}-tile{cfg[1]}-rpl{cfg[2]}")
+    return table.get(f"{workload}/{cfg}")
 
 
 def cpu_baseline(mesh, frame, W, H, budget_s: float = 15.0):
@@ -206,11 +206,13 @@ def main() -> None:
         nominal = F_TEST * tests_per_launch / (sweep_ms_avg * 1e-3) / 1e12 if sweep_ms_avg > 0 else 0.0
         import ctypes as C
         from raytracer_amd import _lib
-        cfg = [C.c_int() for _ in range(4)]
-        _lib.load().rt_sweep_config(*[C.byref(c) for c in cfg])
-        f_exec = float(cfg[3].value)
+        tile, ppl, spl = C.c_int(), C.c_int(), C.c_int()
+        f_primary, f_shadow = C.c_double(), C.c_double()
+        _lib.load().rt_apex_sweep_config(C.byref(tile), C.byref(ppl), C.byref(f_primary), C.byref(spl),
+                                         C.byref(f_shadow))
+        f_exec = f_primary.value
         achieved = nominal * f_exec / F_TEST      # flops the hot loop really executes
-        traffic = measured_traffic(args.workload, [c.value for c in cfg]) if world == 1 else None
+        traffic = measured_traffic(args.workload, f"raster-tile{tile.value}-ppl{ppl.value}") if world == 1 else None
         res = {
             "metric": "Mrays/s and ray-tri tests/s (% fp32 peak) at 1/2/4/8 MI355X vs host-CPU ref",
             "value": (rays_p + rays_s) / (wall / steps) / 1e6,
@@ -234,10 +236,11 @@ def main() -> None:
             "overflow_rays_per_frame": tsum[9].item() / steps,
             # Roofline of the dominant kernel.  `achieved` prices a ray-triangle pair at the fp32
             # flops the hot loop executes for it (rocprof SQ_INSTS_VALU_{ADD,MUL,FMA}_F32, see
-            # profiles/), because the kernel evaluates the test lazily; the nominal 46 flop of a
-            # full Moller-Trumbore test with its divisions is given beside it, not instead of it.
+            # profiles/), because the kernel shares arithmetic between the pixels of a lane and
+            # evaluates the test lazily; the nominal 46 flop of a full Moller-Trumbore test with
+            # its divisions is given beside it, not instead of it.
             "roofline": {
-                "bound": "valu-fp32", "kernel": "k_sweep<primary,closest>",
+                "bound": "valu-fp32", "kernel": "k_sweep_raster (primary rays, closest hit)",
                 "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS,
                 "avg_launch_ms": sweep_ms_avg, "tests_per_launch": tests_per_launch,
@@ -247,7 +250,8 @@ def main() -> None:
                 "traffic_source": traffic["source"] if traffic else None,
                 "flop_per_test_nominal": F_TEST, "achieved_nominal": nominal,
                 "frac_nominal": nominal / PEAK_FP32_TFLOPS,
-                "sweep_kernel": {"form": cfg[0].value, "tile_tris": cfg[1].value, "rays_per_lane": cfg[2].value},
+                "sweep_kernel": {"tile_tris": tile.value, "pixels_per_lane": ppl.value,
+                                 "shadow_rays_per_lane": spl.value, "shadow_flop_per_test": f_shadow.value},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -31,9 +31,21 @@
 // at wave-uniform addresses (broadcast, no bank conflicts).
 #include "rt_sweep_common.h"
 
+#ifndef RT_PREFETCH2
+#define RT_PREFETCH2 0
+#endif
+#ifndef RT_APEX_UNROLL
+#define RT_APEX_UNROLL 4
+#endif
+#ifndef RT_RASTER_UNROLL
+#define RT_RASTER_UNROLL 4
+#endif
+
 namespace {
 
 using namespace rt_sweep;
+constexpr int kRasterUnroll = RT_RASTER_UNROLL;
+constexpr int kApexUnroll = RT_APEX_UNROLL;
 
 struct Tri2 { float4 P, Q; };
 __device__ __forceinline__ Tri2 load_tri2(const float4* p) { return {p[0], p[RT_TILE]}; }
@@ -108,11 +120,20 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_raster(const Swee
         const int tri0 = t * RT_TILE;
         // LDS reads are issued one triangle ahead by hand (the rare path splits the body into
         // basic blocks, which keeps the compiler from hoisting them)
+#if RT_PREFETCH2
+        Tri2 next = load_tri2(base), next2 = load_tri2(base + 1);
+#else
         Tri2 next = load_tri2(base);
-#pragma unroll 2
+#endif
+#pragma unroll kRasterUnroll
         for (int j = 0; j < RT_TILE; ++j) {
             const Tri2 cur = next;
+#if RT_PREFETCH2
+            next = next2;
+            next2 = load_tri2(base + ((j + 2) & (RT_TILE - 1)));    // the last two iterations re-read entries 0, 1 (unused)
+#else
             next = load_tri2(base + ((j + 1) & (RT_TILE - 1)));     // last iteration re-reads entry 0 (unused)
+#endif
             const float yu = __builtin_fmaf(Y, cur.P.y, cur.P.z);
             const float yw = __builtin_fmaf(Y, cur.Q.y, cur.Q.z);
             float s[R];
@@ -249,7 +270,7 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_apex(const SweepA
         const float4* __restrict__ base = tile[buf][0];
         const int tri0 = t * RT_TILE;
         Tri2 next = load_tri2(base);
-#pragma unroll 2
+#pragma unroll kApexUnroll
         for (int j = 0; j < RT_TILE; ++j) {
             const Tri2 cur = next;
             next = load_tri2(base + ((j + 1) & (RT_TILE - 1)));
