@@ -95,8 +95,10 @@ extern "C" int rt_apex_sweep_config(int* tile_tris, int* primary_pixels_per_lane
                                     double* shadow_flop_per_pair)
 {
     if (tile_tris) *tile_tris = RT_TILE;
-    if (primary_pixels_per_lane) *primary_pixels_per_lane = RT_RASTER_RPL;
-    if (primary_flop_per_pair) *primary_flop_per_pair = RT_RASTER_FLOP_PER_PAIR;
+    // of the most recent primary sweep (the launcher shares less per lane on small images)
+    const int rpl = rt_g().last_raster_rpl > 0 ? rt_g().last_raster_rpl : RT_RASTER_RPL;
+    if (primary_pixels_per_lane) *primary_pixels_per_lane = rpl;
+    if (primary_flop_per_pair) *primary_flop_per_pair = rt_raster_flop_per_pair(rpl);
     if (shadow_rays_per_lane) *shadow_rays_per_lane = RT_APEX_RPL;
     if (shadow_flop_per_pair) *shadow_flop_per_pair = RT_APEX_FLOP_PER_PAIR;
     return RT_OK;
@@ -537,9 +539,11 @@ extern "C" int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int
     a.cnt = sc->ws_cnt.as<int32_t>(); a.list = sc->ws_list.as<int32_t>();
     a.tests = nullptr;
     a.tri_begin = 0; a.tri_end = sc->num_tris_padded;
-    const int tiles_x = (W + RT_RASTER_TILE_W - 1) / RT_RASTER_TILE_W;
+    const int rpl = rt_raster_pixels_per_lane(W, y1 - y0);
+    const int tiles_x = (W + 16 * rpl - 1) / (16 * rpl);
     const int tiles_y = (y1 - y0 + RT_TILE_H - 1) / RT_TILE_H;
-    const uint64_t tests = (uint64_t)tiles_x * tiles_y * (RT_WG * RT_RASTER_RPL) * (uint64_t)sc->num_tris_padded;
+    const uint64_t tests = (uint64_t)tiles_x * tiles_y * (RT_WG * rpl) * (uint64_t)sc->num_tris_padded;
+    g.last_raster_rpl = rpl;
     RT_TRY(timed_sweep([&] { return rt_launch_sweep_raster(a, st); }, false, tests, nullptr));
     g.prof.rays_primary += npix;
 
@@ -570,6 +574,8 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, Launch&& launch)
     int first = np / 64;
     first = ((first + RT_TILE - 1) / RT_TILE) * RT_TILE;
     if (first < 16 * RT_TILE) first = 16 * RT_TILE;
+    // a sweep of a few milliseconds is not worth the compaction round trips
+    if ((double)np * (double)n < 1.5e10) first = np;
     int begin = 0, len = first, live = n, cur = 0;
     bool indexed = false;
     while (begin < np && live > 0) {

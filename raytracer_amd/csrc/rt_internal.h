@@ -64,12 +64,10 @@ constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
 #define RT_APEX_RPL 4       // rays per lane of the any-hit apex sweep
 #endif
 constexpr int RT_APEX_PLANES = 4;
-constexpr int RT_RASTER_TILE_W = 16 * RT_RASTER_RPL;   // workgroup = 2x2 waves of (8*RPL) x 8 pixels
-constexpr int RT_APEX_TILE_W = 16 * RT_APEX_RPL;
 // fp32 flops per pair in the hot loops (FMA = 2).  Pixel-grid sweep, per lane and triangle:
 // 2 row terms + 2 FMA per pixel for the two plane distances + 1 FMA per pixel for the
 // slab product.  Apex sweep: two 3-term dot products (1 mul + 2 FMA each) + 1 FMA.
-constexpr double RT_RASTER_FLOP_PER_PAIR = (2.0 * 2 + RT_RASTER_RPL * 3 * 2.0) / RT_RASTER_RPL;
+constexpr double rt_raster_flop_per_pair(int rpl) { return (2.0 * 2 + rpl * 3 * 2.0) / rpl; }
 constexpr double RT_APEX_FLOP_PER_PAIR = 12.0;
 
 // per-ray candidate counter written by the sweep: low bits = candidates pushed, plus
@@ -142,6 +140,7 @@ struct RtGlobal {
     int device = -1;
     hipStream_t stream = nullptr;
     bool profiling = false;
+    int last_raster_rpl = 0;    // pixels per lane of the most recent primary sweep
     rt_profile prof{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -181,6 +180,7 @@ struct SweepArgs {
 int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st);
 // rt_sweep_apex.hip: a.planes = apex planes (RT_APEX_PLANES of them)
 int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st);   // primary rays, closest hit
+int rt_raster_pixels_per_lane(int W, int rows);                   // what that launch will use (<= RT_RASTER_RPL)
 int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st);     // any-hit; tiled (W > 0) or indexed
 int rt_launch_compact(const int32_t* cnt, const int32_t* in, int n, int32_t* out, int* out_count,
                       hipStream_t st);

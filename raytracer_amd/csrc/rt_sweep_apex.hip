@@ -343,6 +343,31 @@ int check_common(const SweepArgs& a)
 
 }  // namespace
 
+static int device_cus()
+{
+    static int cus = 0;         // the device query is slow: once per process
+    if (cus == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+    }
+    return cus;
+}
+
+// Pixels per lane for a band of W x rows pixels: the most sharing (RT_RASTER_RPL) when that
+// still gives every CU about four workgroups, fewer for small images.
+int rt_raster_pixels_per_lane(int W, int rows)
+{
+    const int cus = device_cus();
+    const long tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
+    int r = RT_RASTER_RPL;
+    while (r > 1 && (long)((W + 16 * r - 1) / (16 * r)) * tiles_y < 4L * cus) r /= 2;
+    return r;
+}
+
 int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
 {
     int rc = check_common(a);
@@ -351,9 +376,45 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
         rt_set_error("raster sweep: empty band");
         return RT_E_ARG;
     }
-    const int tiles_x = (a.W + RT_RASTER_TILE_W - 1) / RT_RASTER_TILE_W;
+    const int r = rt_raster_pixels_per_lane(a.W, a.y1 - a.y0);
+    const int tiles_x = (a.W + 16 * r - 1) / (16 * r);
     const int tiles_y = (a.y1 - a.y0 + RT_TILE_H - 1) / RT_TILE_H;
-    return launch(k_sweep_raster<RT_RASTER_RPL>, a, dim3(tiles_x * tiles_y), st, "raster sweep");
+    const dim3 grid(tiles_x * tiles_y);
+    switch (r) {
+    case 1: return launch(k_sweep_raster<1>, a, grid, st, "raster sweep");
+    case 2: return launch(k_sweep_raster<2>, a, grid, st, "raster sweep");
+    case 4: return launch(k_sweep_raster<4>, a, grid, st, "raster sweep");
+    case 8: return launch(k_sweep_raster<8>, a, grid, st, "raster sweep");
+#if RT_RASTER_RPL > 8
+    case RT_RASTER_RPL: return launch(k_sweep_raster<RT_RASTER_RPL>, a, grid, st, "raster sweep");
+#endif
+    }
+    rt_set_error("raster sweep: unsupported pixels per lane %d", r);
+    return RT_E_ARG;
+}
+
+// Rays per lane of an any-hit launch over n rays: RT_APEX_RPL when that still gives every CU
+// about four workgroups, fewer for small batches (more workgroups, same work per pair).
+static int apex_rays_per_lane(long n)
+{
+    int r = RT_APEX_RPL;
+    while (r > 1 && n / (RT_WG * r) < 4L * device_cus()) r /= 2;
+    return r;
+}
+
+template <int MODE>
+static int launch_apex(const SweepArgs& a, int r, unsigned wgs, hipStream_t st)
+{
+    switch (r) {
+    case 1: return launch(k_sweep_apex<MODE, 1>, a, dim3(wgs), st, "apex sweep");
+    case 2: return launch(k_sweep_apex<MODE, 2>, a, dim3(wgs), st, "apex sweep");
+    case 4: return launch(k_sweep_apex<MODE, 4>, a, dim3(wgs), st, "apex sweep");
+#if RT_APEX_RPL > 4
+    case RT_APEX_RPL: return launch(k_sweep_apex<MODE, RT_APEX_RPL>, a, dim3(wgs), st, "apex sweep");
+#endif
+    }
+    rt_set_error("apex sweep: unsupported rays per lane %d", r);
+    return RT_E_ARG;
 }
 
 int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
@@ -366,15 +427,16 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
     }
     if (a.active) {     // indexed: n_rays entries of `active` name the rays
         if (a.n_rays <= 0) return RT_OK;
-        const int per_wg = RT_WG * RT_APEX_RPL;
-        return launch(k_sweep_apex<APEX_INDEXED, RT_APEX_RPL>, a, dim3((a.n_rays + per_wg - 1) / per_wg),
-                      st, "apex sweep");
+        const int r = apex_rays_per_lane(a.n_rays);
+        const int per_wg = RT_WG * r;
+        return launch_apex<APEX_INDEXED>(a, r, (unsigned)((a.n_rays + per_wg - 1) / per_wg), st);
     }
     if (a.W <= 0 || a.y1 <= a.y0) {
         rt_set_error("apex sweep: empty band");
         return RT_E_ARG;
     }
-    const int tiles_x = (a.W + RT_APEX_TILE_W - 1) / RT_APEX_TILE_W;
+    const int r = apex_rays_per_lane((long)a.W * (a.y1 - a.y0));
+    const int tiles_x = (a.W + 16 * r - 1) / (16 * r);
     const int tiles_y = (a.y1 - a.y0 + RT_TILE_H - 1) / RT_TILE_H;
-    return launch(k_sweep_apex<APEX_TILED, RT_APEX_RPL>, a, dim3(tiles_x * tiles_y), st, "apex sweep");
+    return launch_apex<APEX_TILED>(a, r, (unsigned)(tiles_x * tiles_y), st);
 }
