@@ -110,7 +110,7 @@ def main() -> None:
 
     import torch
     import torch.distributed as dist
-    from raytracer_amd import kernel
+    from raytracer_amd import kernel, parallel
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,10 +139,11 @@ def main() -> None:
     frame = frames[0]
     step_no = [0]
     sc = kernel.Scene(mesh, device=local_rank)
-    y0, y1 = kernel.band(H, world, rank)
-    rows = y1 - y0
-    max_rows = (H + world - 1) // world
-    # outputs live in HBM for the whole run; the gather buffer is padded to the tallest band
+    # rows are dealt to the ranks in interleaved blocks of 16 (one rank: the whole image)
+    my_rows = parallel.part_rows(H, world, rank)
+    rows = kernel.rows_count(my_rows)
+    max_rows = parallel.max_part_rows(H, world)
+    # outputs live in HBM for the whole run; the gather buffer is padded to the largest part
     out = {"hit": torch.empty((rows, W), dtype=torch.int32, device=dev),
            "rgb8": torch.zeros((max_rows, W, 3), dtype=torch.uint8, device=dev)}
     gathered = ([torch.empty((max_rows, W, 3), dtype=torch.uint8, device=dev) for _ in range(world)]
@@ -153,7 +154,7 @@ def main() -> None:
         k = step_no[0] % len(frames)
         step_no[0] += 1
         sc.transform(obmats[k])                   # driver.c:110 on the device-resident mesh
-        sc.render_rows(frames[k], W, H, TAN_HALF, y0, y1, want=("hit", "rgb8"),
+        sc.render_rows(frames[k], W, H, TAN_HALF, want=("hit", "rgb8"), rows_set=my_rows,
                        out={"hit": out["hit"], "rgb8": out["rgb8"][:rows]})
         if use_dist:
             if world > 1:
@@ -162,10 +163,9 @@ def main() -> None:
                 dist.gather(out["rgb8"], gathered, dst=0)
             if rank == 0:
                 for r in range(world):
-                    a, b = kernel.band(H, world, r)
-                    sc.place_rows(gathered[r][: b - a], W, H, a, b, screen)
+                    sc.place_rows(gathered[r], W, H, screen=screen, rows_set=parallel.part_rows(H, world, r))
         else:
-            sc.place_rows(out["rgb8"][:rows], W, H, y0, y1, screen)
+            sc.place_rows(out["rgb8"], W, H, screen=screen, rows_set=my_rows)
 
     def fence():
         if use_dist:
@@ -206,10 +206,10 @@ def main() -> None:
         nominal = F_TEST * tests_per_launch / (sweep_ms_avg * 1e-3) / 1e12 if sweep_ms_avg > 0 else 0.0
         import ctypes as C
         from raytracer_amd import _lib
-        tile, ppl, spl = C.c_int(), C.c_int(), C.c_int()
+        tile, ppl, spl, chunks = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         f_primary, f_shadow = C.c_double(), C.c_double()
         _lib.load().rt_apex_sweep_config(C.byref(tile), C.byref(ppl), C.byref(f_primary), C.byref(spl),
-                                         C.byref(f_shadow))
+                                         C.byref(f_shadow), C.byref(chunks))
         f_exec = f_primary.value
         achieved = nominal * f_exec / F_TEST      # flops the hot loop really executes
         traffic = measured_traffic(args.workload, f"raster-tile{tile.value}-ppl{ppl.value}") if world == 1 else None
@@ -226,7 +226,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": args.workload, "mesh": mesh.name, "triangles": mesh.num_tris,
                        "width": W, "height": H, "lights": frame.num_lights,
-                       "sharding": f"{world} row band(s), RCCL gather to rank 0" if world > 1 else "single GPU"},
+                       "sharding": f"{world} interleaved row parts (16-row blocks), RCCL gather to rank 0" if world > 1 else "single GPU"},
             "frames_per_s": steps / wall,
             "primary_mrays_per_s": rays_p / (wall / steps) / 1e6,
             "rays_per_frame": {"primary": rays_p, "shadow": rays_s},
@@ -251,6 +251,7 @@ def main() -> None:
                 "flop_per_test_nominal": F_TEST, "achieved_nominal": nominal,
                 "frac_nominal": nominal / PEAK_FP32_TFLOPS,
                 "sweep_kernel": {"tile_tris": tile.value, "pixels_per_lane": ppl.value,
+                                 "triangle_chunks": chunks.value,
                                  "shadow_rays_per_lane": spl.value, "shadow_flop_per_test": f_shadow.value},
             },
         }

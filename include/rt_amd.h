@@ -156,6 +156,25 @@ int rt_place_rows(const uint8_t* rgb8, int W, int H, int y0, int y1, uint8_t* sc
 /* Row band of rank r out of n: contiguous, remainder to the last ranks one row each. */
 int rt_band(int H, int nranks, int rank, int* y0, int* y1);
 
+/* A row set that interleaves parts: of the rows [y0,y1), cut into blocks of `block` rows, part
+ * `part` of `parts` holds blocks part, part + parts, part + 2*parts, ...  Its rows are numbered
+ * locally 0 .. rt_rows_count()-1 in ascending image order, and the outputs of the *_part calls
+ * are indexed [local_row * W + x_pix].  parts = 1 is the contiguous band.  Interleaving is how
+ * the pixel loop of driver.c:126-193 is split over GPUs when the cost per row is uneven (the
+ * shadow rays of light_model.c:70 are): every part sees every region of the image. */
+typedef struct rt_rows {
+    int y0, y1;      /* image rows the set is cut from */
+    int block;       /* rows per block (16 matches the sweeps' pixel tiles) */
+    int parts, part;
+} rt_rows;
+int rt_rows_count(const rt_rows* rows);                    /* rows in the part, or RT_E_ARG */
+int rt_rows_image_row(const rt_rows* rows, int local_row); /* image row of a local row, or RT_E_ARG */
+int rt_trace_primary_part(rt_scene* sc, int W, int H, double tan_half, const rt_rows* rows,
+                          int32_t* hit, double* tuv);
+int rt_render_rows_part(rt_scene* sc, const rt_frame* f, int W, int H, double tan_half,
+                        const rt_rows* rows, int32_t* hit, double* tuv, double* argb, uint8_t* rgb8);
+int rt_place_rows_part(const uint8_t* rgb8, int W, int H, const rt_rows* rows, uint8_t* screen);
+
 /* ------------------------------------------------------------------ measurement */
 typedef struct rt_profile {
     double   sweep_ms;        /* sum of HIP-event durations of closest-hit sweep launches */
@@ -178,7 +197,7 @@ int rt_sweep_config(int* form, int* tile_tris, int* rays_per_lane, int* flop_per
  * pixel-grid sweep of the primary rays and the per-light any-hit sweep of the shadow rays. */
 int rt_apex_sweep_config(int* tile_tris, int* primary_pixels_per_lane,
                          double* primary_flop_per_pair, int* shadow_rays_per_lane,
-                         double* shadow_flop_per_pair);
+                         double* shadow_flop_per_pair, int* primary_chunks);
 int rt_profile_enable(int on);     /* wraps sweep launches in HIP events and reads the device
                                       counters back (adds a sync per launch); the ray and
                                       candidate counts above are only collected while on */

@@ -35,6 +35,12 @@ class RtFrame(C.Structure):
     ]
 
 
+class RtRows(C.Structure):
+    """rt_rows: part `part` of `parts` of the rows [y0,y1), interleaved in blocks of `block` rows."""
+
+    _fields_ = [("y0", C.c_int), ("y1", C.c_int), ("block", C.c_int), ("parts", C.c_int), ("part", C.c_int)]
+
+
 class RtProfile(C.Structure):
     _fields_ = [
         ("sweep_ms", C.c_double),
@@ -96,9 +102,16 @@ SIGNATURES = {
                                  C.c_int, C.c_int] + [C.c_void_p] * 4),
     "rt_place_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rt_band": (C.c_int, [C.c_int, C.c_int, C.c_int, c_int_p, c_int_p]),
+    "rt_rows_count": (C.c_int, [C.POINTER(RtRows)]),
+    "rt_rows_image_row": (C.c_int, [C.POINTER(RtRows), C.c_int]),
+    "rt_trace_primary_part": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(RtRows),
+                                        C.c_void_p, C.c_void_p]),
+    "rt_render_rows_part": (C.c_int, [C.c_void_p, C.POINTER(RtFrame), C.c_int, C.c_int, C.c_double,
+                                      C.POINTER(RtRows)] + [C.c_void_p] * 4),
+    "rt_place_rows_part": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(RtRows), C.c_void_p]),
     "rt_sweep_config": (C.c_int, [c_int_p] * 4),
     "rt_apex_sweep_config": (C.c_int, [c_int_p, c_int_p, C.POINTER(C.c_double), c_int_p,
-                                       C.POINTER(C.c_double)]),
+                                       C.POINTER(C.c_double), c_int_p]),
     "rt_profile_enable": (C.c_int, [C.c_int]),
     "rt_profile_reset": (C.c_int, []),
     "rt_profile_get": (C.c_int, [C.POINTER(RtProfile)]),

@@ -92,11 +92,12 @@ extern "C" int rt_sweep_config(int* form, int* tile_tris, int* rays_per_lane, in
 
 extern "C" int rt_apex_sweep_config(int* tile_tris, int* primary_pixels_per_lane,
                                     double* primary_flop_per_pair, int* shadow_rays_per_lane,
-                                    double* shadow_flop_per_pair)
+                                    double* shadow_flop_per_pair, int* primary_chunks)
 {
     if (tile_tris) *tile_tris = RT_TILE;
     // of the most recent primary sweep (the launcher shares less per lane on small images)
     const int rpl = rt_g().last_raster_rpl > 0 ? rt_g().last_raster_rpl : RT_RASTER_RPL;
+    if (primary_chunks) *primary_chunks = rt_g().last_raster_chunks > 0 ? rt_g().last_raster_chunks : 1;
     if (primary_pixels_per_lane) *primary_pixels_per_lane = rpl;
     if (primary_flop_per_pair) *primary_flop_per_pair = rt_raster_flop_per_pair(rpl);
     if (shadow_rays_per_lane) *shadow_rays_per_lane = RT_APEX_RPL;
@@ -162,7 +163,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex,
                       &sc->scratch_max, &sc->mat_dev, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
-                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1};
+                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_live};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : sc->tex_data) b.release();
     delete sc;
@@ -512,70 +513,139 @@ static int fetch_counters(rt_scene* sc, bool sync_always)
     return RT_OK;
 }
 
-extern "C" int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int y0, int y1,
-                                int32_t* hit, double* tuv)
+// ---- row sets (rt_rows in the public header -> RowMap)
+static int rows_of_part(const rt_rows* r)
 {
-    RT_TRY(require_ready(sc));
-    RT_ARG(hit, "null hit buffer");
-    RT_ARG(W > 0 && H > 0 && y0 >= 0 && y1 <= H && y0 < y1, "bad image size or row band");
-    RT_ARG(tan_half > 0, "tan_half must be positive");
+    if (!r || r->block <= 0 || r->parts <= 0 || r->part < 0 || r->part >= r->parts || r->y1 < r->y0)
+        return -1;
+    const int total = r->y1 - r->y0;
+    const int nblocks = (total + r->block - 1) / r->block;
+    int rows = 0;
+    for (int b = r->part; b < nblocks; b += r->parts) {
+        const int left = total - b * r->block;
+        rows += left < r->block ? left : r->block;
+    }
+    return rows;
+}
+
+extern "C" int rt_rows_count(const rt_rows* r)
+{
+    const int n = rows_of_part(r);
+    if (n < 0) {
+        rt_set_error("rt_rows_count: bad row set");
+        return RT_E_ARG;
+    }
+    return n;
+}
+
+extern "C" int rt_rows_image_row(const rt_rows* r, int local_row)
+{
+    const int n = rows_of_part(r);
+    if (n < 0 || local_row < 0 || local_row >= n) {
+        rt_set_error("rt_rows_image_row: bad row set or row");
+        return RT_E_ARG;
+    }
+    return RowMap{r->y0, n, r->block, r->parts, r->part}.image_row(local_row);
+}
+
+static int row_map(const rt_rows* r, int H, RowMap* out)
+{
+    const int n = rows_of_part(r);
+    if (n < 0 || r->y0 < 0 || r->y1 > H) {
+        rt_set_error("bad row set (need 0 <= y0 <= y1 <= H, block > 0, 0 <= part < parts)");
+        return RT_E_ARG;
+    }
+    *out = RowMap{r->y0, n, r->block, r->parts, r->part};
+    return RT_OK;
+}
+
+static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const RowMap& rows,
+                              int32_t* hit, double* tuv)
+{
     RtGlobal& g = rt_g();
     hipStream_t st = g.stream;
-    const size_t npix = (size_t)W * (y1 - y0);
-    RT_TRY(workspaces(sc, npix));
+    const size_t npix = (size_t)W * rows.rows;
+    int rpl = 1, chunks = 1;
+    rt_raster_shape(W, rows.rows, sc->num_tris_padded / RT_TILE, &rpl, &chunks);
+    RT_TRY(workspaces(sc, npix * (size_t)chunks));
     RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
 
     // planes for rays from the eye; the constant z of the pixel-grid directions is folded in
     const double ez = (double)(W / 2) / tan_half;       // driver.c:133
     const double eye[3] = {0, 0, 0};                    // driver.c:121-123
     const double hw = 0.5 * W + 1, hh = 0.5 * H + 1;
-    RT_TRY(rt_launch_pack_apex(sc, eye, ez, sqrt(hw * hw + hh * hh + ez * ez), st));
+    RT_TRY(rt_launch_pack_apex(sc, eye, ez, sqrt(hw * hw + hh * hh + ez * ez), 0, st));
 
     SweepArgs a{};
     a.planes = sc->planes_apex.as<float4>(); a.plane_stride = sc->num_tris_padded;
     a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
-    a.W = W; a.H = H; a.y0 = y0; a.y1 = y1;
+    a.W = W; a.H = H; a.rows = rows;
     a.ez = ez;
     a.cnt = sc->ws_cnt.as<int32_t>(); a.list = sc->ws_list.as<int32_t>();
+    a.chunks = chunks; a.chunk_stride = (long)npix;
     a.tests = nullptr;
     a.tri_begin = 0; a.tri_end = sc->num_tris_padded;
-    const int rpl = rt_raster_pixels_per_lane(W, y1 - y0);
     const int tiles_x = (W + 16 * rpl - 1) / (16 * rpl);
-    const int tiles_y = (y1 - y0 + RT_TILE_H - 1) / RT_TILE_H;
+    const int tiles_y = (rows.rows + RT_TILE_H - 1) / RT_TILE_H;
     const uint64_t tests = (uint64_t)tiles_x * tiles_y * (RT_WG * rpl) * (uint64_t)sc->num_tris_padded;
     g.last_raster_rpl = rpl;
+    g.last_raster_chunks = chunks;
     RT_TRY(timed_sweep([&] { return rt_launch_sweep_raster(a, st); }, false, tests, nullptr));
     g.prof.rays_primary += npix;
 
     const ExactScene es = exact_of(sc);
     int* counters = sc->ws_counters.as<int>();
-    RT_TRY(rt_launch_resolve_primary(es, W, H, tan_half, y0, y1, a.cnt, a.list, hit, tuv,
-                                     sc->ws_ovf.as<int32_t>(), counters, st));
-    RT_TRY(rt_launch_overflow_primary(es, W, H, tan_half, y0, sc->ws_ovf.as<int32_t>(), counters,
+    RT_TRY(rt_launch_resolve_primary(es, W, H, tan_half, rows, a.cnt, a.list, chunks, a.chunk_stride,
+                                     hit, tuv, sc->ws_ovf.as<int32_t>(), counters, st));
+    RT_TRY(rt_launch_overflow_primary(es, W, H, tan_half, rows, sc->ws_ovf.as<int32_t>(), counters,
                                       hit, tuv, st));
     RT_TRY(fetch_counters(sc, false));
     RT_HIP(hipStreamSynchronize(st));
     return RT_OK;
 }
 
+extern "C" int rt_trace_primary_part(rt_scene* sc, int W, int H, double tan_half, const rt_rows* rows,
+                                     int32_t* hit, double* tuv)
+{
+    RT_TRY(require_ready(sc));
+    RT_ARG(hit, "null hit buffer");
+    RT_ARG(W > 0 && H > 0, "bad image size");
+    RT_ARG(tan_half > 0, "tan_half must be positive");
+    RowMap rm;
+    RT_TRY(row_map(rows, H, &rm));
+    if (rm.rows == 0) return RT_OK;
+    return trace_primary_rows(sc, W, H, tan_half, rm, hit, tuv);
+}
+
+extern "C" int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int y0, int y1,
+                                int32_t* hit, double* tuv)
+{
+    RT_ARG(y0 < y1, "bad image size or row band");
+    const rt_rows r = {y0, y1, y1 - y0, 1, 0};
+    return rt_trace_primary_part(sc, W, H, tan_half, &r, hit, tuv);
+}
+
 // Any-hit sweep in triangle ranges of doubling length; the survivors are compacted between
 // ranges, so a ray's cost becomes ~ the index of its first certain occluder, not the mesh
-// size.  `a` describes the first range's launch (all n rays); later ranges run indexed over
-// the survivor list.  launch(a) starts one range.
+// size.  `a` describes the first range's launch over `sets` ray sets of n rays each (sets > 1:
+// the shadow rays of several lights, stride rays apart); later ranges run indexed over the
+// survivor lists.  launch(a) starts one range for all sets.
 template <class Launch>
-static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, Launch&& launch)
+static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride, Launch&& launch)
 {
     hipStream_t st = rt_g().stream;
     const int np = sc->num_tris_padded;
-    RT_TRY(sc->ws_act0.reserve(sizeof(int32_t) * (size_t)n));
-    RT_TRY(sc->ws_act1.reserve(sizeof(int32_t) * (size_t)n));
+    RT_ARG(sets >= 1 && sets <= RT_APEX_SETS, "too many ray sets for one launch");
+    RT_TRY(sc->ws_act0.reserve(sizeof(int32_t) * (size_t)stride * sets));
+    RT_TRY(sc->ws_act1.reserve(sizeof(int32_t) * (size_t)stride * sets));
+    RT_TRY(sc->ws_live.reserve(sizeof(int) * 2 * RT_APEX_SETS));
     int32_t* act[2] = {sc->ws_act0.as<int32_t>(), sc->ws_act1.as<int32_t>()};
-    int* live_count = sc->ws_counters.as<int>() + 8;        // counters[8]
+    int* live_dev[2] = {sc->ws_live.as<int>(), sc->ws_live.as<int>() + RT_APEX_SETS};
     int first = np / 64;
     first = ((first + RT_TILE - 1) / RT_TILE) * RT_TILE;
     if (first < 16 * RT_TILE) first = 16 * RT_TILE;
     // a sweep of a few milliseconds is not worth the compaction round trips
-    if ((double)np * (double)n < 1.5e10) first = np;
+    if ((double)np * (double)n * sets < 1.5e10) first = np;
     int begin = 0, len = first, live = n, cur = 0;
     bool indexed = false;
     while (begin < np && live > 0) {
@@ -584,19 +654,25 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, Launch&& launch)
         a.tri_begin = begin; a.tri_end = end;
         a.resume = begin > 0;
         a.active = indexed ? act[cur] : nullptr;
-        a.n_rays = indexed ? live : n;
+        a.live_counts = indexed ? live_dev[cur] : nullptr;
+        a.n_rays = indexed ? live : n;          // indexed: the largest set, sizes the grid
+        a.lights = sets;
+        a.light_ray_stride = stride;
         RT_TRY(timed_sweep([&] { return launch(a); }, true, 0, a.tests));
         if (getenv("RT_AMD_TRACE_PASSES"))
-            fprintf(stderr, "rt_amd: any-hit range [%d,%d) over %d rays\n", begin, end,
-                    indexed ? live : n);
+            fprintf(stderr, "rt_amd: any-hit range [%d,%d) over %d set(s) of at most %d rays\n", begin,
+                    end, sets, indexed ? live : n);
         begin = end;
         if (begin >= np) break;
-        // compact the survivors (first time from the full range, then from the last list)
-        RT_HIP(hipMemsetAsync(live_count, 0, sizeof(int), st));
-        RT_TRY(rt_launch_compact(a.cnt, indexed ? act[cur] : nullptr, indexed ? live : n,
-                                 act[cur ^ 1], live_count, st));
-        RT_HIP(hipMemcpyAsync(&live, live_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        // compact the survivors (first time from the full sets, then from the last lists)
+        RT_HIP(hipMemsetAsync(live_dev[cur ^ 1], 0, sizeof(int) * RT_APEX_SETS, st));
+        RT_TRY(rt_launch_compact(a.cnt, indexed ? act[cur] : nullptr, indexed ? live_dev[cur] : nullptr,
+                                 indexed ? live : n, sets, stride, act[cur ^ 1], live_dev[cur ^ 1], st));
+        int counts[RT_APEX_SETS];
+        RT_HIP(hipMemcpyAsync(counts, live_dev[cur ^ 1], sizeof(int) * sets, hipMemcpyDeviceToHost, st));
         RT_HIP(hipStreamSynchronize(st));
+        live = 0;
+        for (int k = 0; k < sets; ++k) live = counts[k] > live ? counts[k] : live;
         cur ^= 1;
         indexed = true;
         len *= 2;
@@ -645,32 +721,38 @@ static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E
         RT_TRY(timed_sweep([&] { return rt_launch_sweep_rays(a, false, st); }, false,
                            wgs * RT_RAYS_PER_WG * (uint64_t)np, a.tests));
     } else {
-        RT_TRY(anyhit_ranges(sc, a, n, [&](const SweepArgs& r) { return rt_launch_sweep_rays(r, true, st); }));
+        RT_TRY(anyhit_ranges(sc, a, n, 1, n, [&](const SweepArgs& r) { return rt_launch_sweep_rays(r, true, st); }));
     }
     return resolve_rays(sc, n, S, E, anyhit, hit, tuv, point, occ);
 }
 
 // Shadow rays of the pixel loop: [light][pixel] rays that end at their light (k_shadow_setup).
-// One apex sweep per light over planes packed relative to that light (rt_sweep_apex.hip).
-static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int y0, int y1,
+// Apex sweeps over planes packed relative to each light (rt_sweep_apex.hip), up to
+// RT_APEX_SETS lights per launch.
+static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows,
                              const double* S, const double* E, uint8_t* occ)
 {
     hipStream_t st = rt_g().stream;
-    const size_t npix = (size_t)W * (y1 - y0);
+    const size_t npix = (size_t)W * nrows;
     const int L = f->num_lights;
     RT_TRY(workspaces(sc, npix * (size_t)L));
     RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
-    for (int l = 0; l < L; ++l) {
-        RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l], 1.0, 1.0, st));
+    for (int l0 = 0; l0 < L; l0 += RT_APEX_SETS) {
+        const int sets = L - l0 < RT_APEX_SETS ? L - l0 : RT_APEX_SETS;
+        RT_TRY(sc->planes_apex.reserve(sizeof(float4) * (size_t)sc->num_tris_padded * RT_APEX_PLANES * sets));
+        for (int k = 0; k < sets; ++k)
+            RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l0 + k], 1.0, 1.0, k, st));
         SweepArgs a{};
         a.planes = sc->planes_apex.as<float4>(); a.plane_stride = sc->num_tris_padded;
+        a.light_plane_stride = (long)RT_APEX_PLANES * sc->num_tris_padded;
         a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
-        a.W = W; a.y0 = y0; a.y1 = y1; a.H = 0;
-        a.S = S + 3 * npix * (size_t)l; a.E = E + 3 * npix * (size_t)l;
-        a.cnt = sc->ws_cnt.as<int32_t>() + npix * (size_t)l;
-        a.list = sc->ws_list.as<int32_t>() + npix * (size_t)l * RT_LIST_K;
+        a.W = W; a.rows = rt_band_rows(0, nrows); a.H = 0;
+        a.S = S + 3 * npix * (size_t)l0; a.E = E + 3 * npix * (size_t)l0;
+        a.cnt = sc->ws_cnt.as<int32_t>() + npix * (size_t)l0;
+        a.list = sc->ws_list.as<int32_t>() + npix * (size_t)l0 * RT_LIST_K;
         a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
-        RT_TRY(anyhit_ranges(sc, a, (int)npix, [&](const SweepArgs& r) { return rt_launch_sweep_apex(r, st); }));
+        RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix,
+                             [&](const SweepArgs& r) { return rt_launch_sweep_apex(r, st); }));
     }
     return resolve_rays(sc, (int)(npix * (size_t)L), S, E, true, nullptr, nullptr, nullptr, occ);
 }
@@ -697,23 +779,17 @@ extern "C" int rt_occluded(rt_scene* sc, int n, const double* S, const double* E
 }
 
 // ---------------------------------------------------------------- whole pixel loop
-extern "C" int rt_render_rows(rt_scene* sc, const rt_frame* f, int W, int H, double tan_half,
-                              int y0, int y1, int32_t* hit, double* tuv, double* argb,
-                              uint8_t* rgb8)
+static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, double tan_half,
+                            const RowMap& rows, int32_t* hit, double* tuv, double* argb, uint8_t* rgb8)
 {
-    RT_TRY(require_ready(sc));
-    RT_ARG(f, "null frame");
-    RT_ARG(f->num_lights >= 0 && f->num_lights <= RT_MAX_LIGHTS, "num_lights outside [0,100]");
-    RT_ARG(W > 0 && H > 0 && y0 >= 0 && y1 <= H && y0 < y1, "bad image size or row band");
-    RT_ARG(sc->iAn.p && sc->nx.p, "scene has no normals (needed for shading)");
     RtGlobal& g = rt_g();
     hipStream_t st = g.stream;
-    const size_t npix = (size_t)W * (y1 - y0);
+    const size_t npix = (size_t)W * rows.rows;
     const int L = f->num_lights;
 
     if (!hit) { RT_TRY(sc->ws_hit.reserve(sizeof(int32_t) * npix)); hit = sc->ws_hit.as<int32_t>(); }
     if (!tuv) { RT_TRY(sc->ws_tuv.reserve(sizeof(double) * 3 * npix)); tuv = sc->ws_tuv.as<double>(); }
-    RT_TRY(rt_trace_primary(sc, W, H, tan_half, y0, y1, hit, tuv));
+    RT_TRY(trace_primary_rows(sc, W, H, tan_half, rows, hit, tuv));
 
     // frame constants
     static DevBuf frame_dev;
@@ -741,7 +817,7 @@ extern "C" int rt_render_rows(rt_scene* sc, const rt_frame* f, int W, int H, dou
     a.num_mats = sc->num_mats;
     a.frame = frame_dev.as<DevFrame>();
     a.num_lights = L;
-    a.W = W; a.H = H; a.y0 = y0; a.y1 = y1; a.tan_half = tan_half;
+    a.W = W; a.H = H; a.rows = rows; a.tan_half = tan_half;
     a.hit = hit; a.tuv = tuv;
     a.argb = argb; a.rgb8 = rgb8;
     if (L > 0) {
@@ -753,21 +829,55 @@ extern "C" int rt_render_rows(rt_scene* sc, const rt_frame* f, int W, int H, dou
         a.shS = sc->ws_shS.as<double>(); a.shE = sc->ws_shE.as<double>();
         a.occ = sc->ws_occ.as<uint8_t>();
         RT_TRY(rt_launch_shadow_setup(a, st));
-        RT_TRY(trace_shadow_rays(sc, f, W, y0, y1, a.shS, a.shE, sc->ws_occ.as<uint8_t>()));
+        RT_TRY(trace_shadow_rays(sc, f, W, rows.rows, a.shS, a.shE, sc->ws_occ.as<uint8_t>()));
     }
     RT_TRY(rt_launch_shade_final(a, st));
     RT_HIP(hipStreamSynchronize(st));
     return RT_OK;
 }
 
-extern "C" int rt_place_rows(const uint8_t* rgb8, int W, int H, int y0, int y1, uint8_t* screen)
+extern "C" int rt_render_rows_part(rt_scene* sc, const rt_frame* f, int W, int H, double tan_half,
+                                   const rt_rows* rows, int32_t* hit, double* tuv, double* argb,
+                                   uint8_t* rgb8)
+{
+    RT_TRY(require_ready(sc));
+    RT_ARG(f, "null frame");
+    RT_ARG(f->num_lights >= 0 && f->num_lights <= RT_MAX_LIGHTS, "num_lights outside [0,100]");
+    RT_ARG(W > 0 && H > 0, "bad image size");
+    RT_ARG(tan_half > 0, "tan_half must be positive");
+    RT_ARG(sc->iAn.p && sc->nx.p, "scene has no normals (needed for shading)");
+    RowMap rm;
+    RT_TRY(row_map(rows, H, &rm));
+    if (rm.rows == 0) return RT_OK;
+    return render_rows_impl(sc, f, W, H, tan_half, rm, hit, tuv, argb, rgb8);
+}
+
+extern "C" int rt_render_rows(rt_scene* sc, const rt_frame* f, int W, int H, double tan_half,
+                              int y0, int y1, int32_t* hit, double* tuv, double* argb,
+                              uint8_t* rgb8)
+{
+    RT_ARG(y0 < y1, "bad image size or row band");
+    const rt_rows r = {y0, y1, y1 - y0, 1, 0};
+    return rt_render_rows_part(sc, f, W, H, tan_half, &r, hit, tuv, argb, rgb8);
+}
+
+extern "C" int rt_place_rows_part(const uint8_t* rgb8, int W, int H, const rt_rows* rows, uint8_t* screen)
 {
     RT_ARG(rgb8 && screen, "null pointer");
-    RT_ARG(W > 0 && H > 0 && y0 >= 0 && y1 <= H && y0 <= y1, "bad image size or row band");
+    RT_ARG(W > 0 && H > 0, "bad image size");
+    RowMap rm;
+    RT_TRY(row_map(rows, H, &rm));
     RT_TRY(rt_ensure_init());
-    RT_TRY(rt_launch_place_rows(rgb8, W, H, y0, y1, screen, rt_g().stream));
+    RT_TRY(rt_launch_place_rows(rgb8, W, H, rm, screen, rt_g().stream));
     RT_HIP(hipStreamSynchronize(rt_g().stream));
     return RT_OK;
+}
+
+extern "C" int rt_place_rows(const uint8_t* rgb8, int W, int H, int y0, int y1, uint8_t* screen)
+{
+    RT_ARG(y0 <= y1, "bad image size or row band");
+    const rt_rows r = {y0, y1, y1 - y0 > 0 ? y1 - y0 : 1, 1, 0};
+    return rt_place_rows_part(rgb8, W, H, &r, screen);
 }
 
 // ---------------------------------------------------------------- the reference's kernel.h API

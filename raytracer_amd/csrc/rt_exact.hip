@@ -84,57 +84,75 @@ struct Best {
     int idx;
 };
 
-// Confirmation of one ray's candidate list.  Returns false when the list overflowed.
+// Confirmation of one ray's candidate lists (one per triangle chunk of the sweep, in ascending
+// triangle order).  Returns false when a list overflowed; ncand = candidates evaluated.
 template <bool ANYHIT>
 __device__ __forceinline__ bool confirm_list(const ExactScene& es, const double S[3],
-                                             const double E[3], int cnt,
-                                             const int32_t* __restrict__ list, Best& best,
-                                             bool& occluded)
+                                             const double E[3], const int32_t* __restrict__ cnt,
+                                             const int32_t* __restrict__ list, long p, int chunks,
+                                             long chunk_stride, Best& best, bool& occluded,
+                                             int& ncand)
 {
     best.t = 1e50;                  // triangle_intersection.cu:108
     best.idx = -1;
     best.u = best.v = 0;
     occluded = false;
-    if (ANYHIT && (cnt & RT_CNT_OCCLUDED)) {
-        occluded = true;
-        return true;
-    }
-    cnt &= RT_CNT_MASK;
-    if (cnt > RT_LIST_K) return false;
-    for (int k = 0; k < cnt; ++k) {
-        const int i = list[k];
-        double u, v;
-        const double dist = exact_tri(es, i, S, E, u, v);
-        if ((dist > 0) && (dist < best.t)) {       // :169
-            best.t = dist; best.u = u; best.v = v; best.idx = i;
-            if (ANYHIT) { occluded = true; return true; }
+    ncand = 0;
+    for (int c = 0; c < chunks; ++c) {
+        int n = cnt[c * chunk_stride + p];
+        if (ANYHIT && (n & RT_CNT_OCCLUDED)) {
+            occluded = true;
+            return true;
+        }
+        n &= RT_CNT_MASK;
+        if (n > RT_LIST_K) return false;
+        ncand += n;
+        const int32_t* l = list + (c * chunk_stride + p) * RT_LIST_K;
+        for (int k = 0; k < n; ++k) {
+            const int i = l[k];
+            double u, v;
+            const double dist = exact_tri(es, i, S, E, u, v);
+            if ((dist > 0) && (dist < best.t)) {       // :169
+                best.t = dist; best.u = u; best.v = v; best.idx = i;
+                if (ANYHIT) { occluded = true; return true; }
+            }
         }
     }
     return true;
 }
 
+// one atomic per wave instead of one per lane
+__device__ __forceinline__ void wave_add(int* counter, int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(counter, v);
+}
+
 __global__ void __launch_bounds__(RT_WG)
-k_resolve_primary(ExactScene es, int W, int H, double tan_half, int y0, int y1,
-                  const int32_t* __restrict__ cnt, const int32_t* __restrict__ list,
-                  int32_t* __restrict__ hit, double* __restrict__ tuv,
+k_resolve_primary(ExactScene es, int W, int H, double tan_half, RowMap rows,
+                  const int32_t* __restrict__ cnt, const int32_t* __restrict__ list, int chunks,
+                  long chunk_stride, int32_t* __restrict__ hit, double* __restrict__ tuv,
                   int32_t* __restrict__ ovf, int* __restrict__ counters)
 {
-    const long npix = (long)W * (y1 - y0);
+    const long npix = (long)W * rows.rows;
     const long p = (long)blockIdx.x * RT_WG + threadIdx.x;
-    if (p >= npix) return;
-    const int py = y0 + (int)(p / W), px = (int)(p % W);
-    double S[3], E[3];
-    primary_ray(W, H, tan_half, px, py, S, E);
-    Best b;
-    bool occ;
-    const int c = cnt[p];
-    if (!confirm_list<false>(es, S, E, c, list + p * RT_LIST_K, b, occ)) {
-        ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
-        return;
+    int ncand = 0;
+    if (p < npix) {
+        const int py = rows.image_row((int)(p / W)), px = (int)(p % W);
+        double S[3], E[3];
+        primary_ray(W, H, tan_half, px, py, S, E);
+        Best b;
+        bool occ;
+        if (!confirm_list<false>(es, S, E, cnt, list, p, chunks, chunk_stride, b, occ, ncand)) {
+            ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
+            ncand = 0;
+        } else {
+            hit[p] = b.idx;
+            if (b.idx != -1 && tuv) { tuv[3 * p] = b.t; tuv[3 * p + 1] = b.u; tuv[3 * p + 2] = b.v; }
+        }
     }
-    atomicAdd(&counters[1], c & RT_CNT_MASK);
-    hit[p] = b.idx;
-    if (b.idx != -1 && tuv) { tuv[3 * p] = b.t; tuv[3 * p + 1] = b.u; tuv[3 * p + 2] = b.v; }
+    wave_add(&counters[1], ncand);
 }
 
 template <bool ANYHIT>
@@ -148,21 +166,24 @@ k_resolve_rays(ExactScene es, int n, const double* __restrict__ Sa, const double
     const bool live = p < n && (Sa[3 * p] == Sa[3 * p]);       // NaN origin = unused ray slot
     const unsigned long long live_mask = __ballot(live);
     if ((threadIdx.x & 63) == 0 && live_mask) atomicAdd(&counters[4], __popcll(live_mask));
-    if (p >= n) return;
-    const double S[3] = {Sa[3 * p], Sa[3 * p + 1], Sa[3 * p + 2]};
-    const double E[3] = {Ea[3 * p], Ea[3 * p + 1], Ea[3 * p + 2]};
-    if (!live) {
+    int ncand = 0;
+    if (p < n && !live) {
         if (ANYHIT) occ_out[p] = 0; else hit[p] = -1;
-        return;
     }
     Best b;
-    bool occ;
-    const int c = cnt[p];
-    if (!confirm_list<ANYHIT>(es, S, E, c, list + p * RT_LIST_K, b, occ)) {
-        ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
-        return;
+    bool occ = false, resolved = false;
+    double S[3] = {0, 0, 0}, E[3] = {0, 0, 0};
+    if (live) {
+        S[0] = Sa[3 * p]; S[1] = Sa[3 * p + 1]; S[2] = Sa[3 * p + 2];
+        E[0] = Ea[3 * p]; E[1] = Ea[3 * p + 1]; E[2] = Ea[3 * p + 2];
+        resolved = confirm_list<ANYHIT>(es, S, E, cnt, list, p, 1, 0, b, occ, ncand);
+        if (!resolved) {
+            ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
+            ncand = 0;
+        }
     }
-    atomicAdd(&counters[1], (c & RT_CNT_OCCLUDED) ? 0 : (c & RT_CNT_MASK));
+    wave_add(&counters[1], ncand);
+    if (!resolved) return;
     if (ANYHIT) {
         occ_out[p] = occ ? 1 : 0;
     } else {
@@ -214,14 +235,14 @@ __device__ __forceinline__ Best full_sweep(const ExactScene& es, const double S[
 }
 
 __global__ void __launch_bounds__(RT_WG)
-k_overflow_primary(ExactScene es, int W, int H, double tan_half, int y0,
+k_overflow_primary(ExactScene es, int W, int H, double tan_half, RowMap rows,
                    const int32_t* __restrict__ ovf, const int* __restrict__ counters,
                    int32_t* __restrict__ hit, double* __restrict__ tuv)
 {
     const int n = counters[0];
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
         const long p = ovf[k];
-        const int py = y0 + (int)(p / W), px = (int)(p % W);
+        const int py = rows.image_row((int)(p / W)), px = (int)(p % W);
         double S[3], E[3];
         primary_ray(W, H, tan_half, px, py, S, E);
         const Best b = full_sweep(es, S, E);
@@ -340,14 +361,14 @@ constexpr int SINGLE_RAY_GRID = 256;
 
 }  // namespace
 
-int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_half, int y0, int y1,
-                              const int32_t* cnt, const int32_t* list, int32_t* hit, double* tuv,
-                              int32_t* ovf, int* counters, hipStream_t st)
+int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_half, const RowMap& rows,
+                              const int32_t* cnt, const int32_t* list, int chunks, long chunk_stride,
+                              int32_t* hit, double* tuv, int32_t* ovf, int* counters, hipStream_t st)
 {
-    const long npix = (long)W * (y1 - y0);
+    const long npix = (long)W * rows.rows;
     if (npix <= 0) return RT_OK;
     hipLaunchKernelGGL(k_resolve_primary, dim3((unsigned)((npix + RT_WG - 1) / RT_WG)), dim3(RT_WG),
-                       0, st, es, W, H, tan_half, y0, y1, cnt, list, hit, tuv, ovf, counters);
+                       0, st, es, W, H, tan_half, rows, cnt, list, chunks, chunk_stride, hit, tuv, ovf, counters);
     return launched("resolve_primary");
 }
 
@@ -367,12 +388,12 @@ int rt_launch_resolve_rays(const ExactScene& es, int n, const double* S, const d
     return launched("resolve_rays");
 }
 
-int rt_launch_overflow_primary(const ExactScene& es, int W, int H, double tan_half, int y0,
+int rt_launch_overflow_primary(const ExactScene& es, int W, int H, double tan_half, const RowMap& rows,
                                const int32_t* ovf, const int* counters, int32_t* hit, double* tuv,
                                hipStream_t st)
 {
     hipLaunchKernelGGL(k_overflow_primary, dim3(OVERFLOW_GRID), dim3(RT_WG), 0, st, es, W, H,
-                       tan_half, y0, ovf, counters, hit, tuv);
+                       tan_half, rows, ovf, counters, hit, tuv);
     return launched("overflow_primary");
 }
 

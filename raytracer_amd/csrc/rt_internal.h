@@ -64,6 +64,7 @@ constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
 #define RT_APEX_RPL 4       // rays per lane of the any-hit apex sweep
 #endif
 constexpr int RT_APEX_PLANES = 4;
+constexpr int RT_APEX_SETS = 8;     // plane sets kept side by side: lights swept per launch
 // fp32 flops per pair in the hot loops (FMA = 2).  Pixel-grid sweep, per lane and triangle:
 // 2 row terms + 2 FMA per pixel for the two plane distances + 1 FMA per pixel for the
 // slab product.  Apex sweep: two 3-term dot products (1 mul + 2 FMA each) + 1 FMA.
@@ -112,7 +113,7 @@ struct rt_scene {
 
     // per-call workspaces (grow-only)
     DevBuf ws_cnt, ws_list, ws_ovf, ws_counters;
-    DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1;
+    DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_live;
 };
 
 struct DevMaterial {
@@ -141,6 +142,7 @@ struct RtGlobal {
     hipStream_t stream = nullptr;
     bool profiling = false;
     int last_raster_rpl = 0;    // pixels per lane of the most recent primary sweep
+    int last_raster_chunks = 0; // and its triangle chunks
     rt_profile prof{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -154,7 +156,21 @@ int rt_launch_transform(const double* m16, const double* x, const double* y, con
 int rt_launch_pack(rt_scene* sc, hipStream_t st);
 // apex planes for rays through `apex`; zs is folded into the z components (the constant z of
 // pixel-grid directions, 1 otherwise); dmax bounds |D| of every ray of the sweep
-int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, hipStream_t st);
+int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, int set,
+                        hipStream_t st);      // into plane set `set` of sc->planes_apex
+
+// The pixel rows one call works on.  Local row lr (0 .. rows-1) is image row
+//     y0 + ((lr / block) * parts + part) * block + lr % block,
+// i.e. every parts-th block of `block` rows starting with block `part`; parts = 1 is the
+// contiguous band [y0, y0 + rows).  Outputs are indexed by local row.
+struct RowMap {
+    int y0, rows, block, parts, part;
+    __host__ __device__ int image_row(int lr) const
+    {
+        return y0 + ((lr / block) * parts + part) * block + lr % block;
+    }
+};
+inline RowMap rt_band_rows(int y0, int y1) { return RowMap{y0, y1 - y0, y1 - y0 > 0 ? y1 - y0 : 1, 1, 0}; }
 
 // rt_sweep.hip
 struct SweepArgs {
@@ -162,7 +178,8 @@ struct SweepArgs {
     long plane_stride;
     int num_tris, num_tris_padded;
     // primary mode
-    int W, H, y0, y1;
+    int W, H;
+    RowMap rows;
     double ez;              // (W/2)/tan_half, integer W/2 (driver.c:133)
     // generic mode
     int n_rays;
@@ -175,15 +192,32 @@ struct SweepArgs {
     // outputs
     int32_t* cnt;           // per ray: candidates pushed | RT_CNT_* flags
     int32_t* list;          // RT_LIST_K candidate triangle indices per ray
+    // apex any-hit sweep only: `lights` ray sets (the shadow rays of several lights) swept by
+    // one launch, set l = blockIdx.y.  Set l has its planes light_plane_stride float4 after set
+    // l-1 and its rays, counts, lists and active entries light_ray_stride rays after; in indexed
+    // mode its number of active entries is live_counts[l] (n_rays is then only the bound the
+    // grid was sized for).
+    int lights;
+    long light_ray_stride, light_plane_stride;
+    const int* live_counts;
+    // pixel-grid sweep only: the triangle range is cut into `chunks` equal parts that run as
+    // separate workgroups; chunk c keeps its counts and lists chunk_stride rays further on
+    int chunks;
+    long chunk_stride;
     unsigned long long* tests;   // pairs evaluated, accumulated per workgroup (may be nullptr)
 };
 int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st);
 // rt_sweep_apex.hip: a.planes = apex planes (RT_APEX_PLANES of them)
 int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st);   // primary rays, closest hit
-int rt_raster_pixels_per_lane(int W, int rows);                   // what that launch will use (<= RT_RASTER_RPL)
+// launch shape of the pixel-grid sweep for a band of W x rows pixels and `tiles` triangle tiles:
+// pixels per lane (<= RT_RASTER_RPL) and the number of triangle chunks (<= RT_RASTER_MAX_CHUNKS)
+constexpr int RT_RASTER_MAX_CHUNKS = 8;
+void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks);
 int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st);     // any-hit; tiled (W > 0) or indexed
-int rt_launch_compact(const int32_t* cnt, const int32_t* in, int n, int32_t* out, int* out_count,
-                      hipStream_t st);
+// survivors of `sets` ray sets (stride rays apart in cnt/in/out): set l takes its n from
+// in_counts[l] when `in` is given, else all n rays; writes out_counts[l]
+int rt_launch_compact(const int32_t* cnt, const int32_t* in, const int* in_counts, int n, int sets,
+                      long stride, int32_t* out, int* out_counts, hipStream_t st);
 
 // rt_exact.hip
 struct ExactScene {
@@ -191,15 +225,15 @@ struct ExactScene {
     const int *A, *B, *C;
     int num_tris;
 };
-int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_half, int y0, int y1,
-                              const int32_t* cnt, const int32_t* list,
+int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_half, const RowMap& rows,
+                              const int32_t* cnt, const int32_t* list, int chunks, long chunk_stride,
                               int32_t* hit, double* tuv, int32_t* ovf, int* counters,
                               hipStream_t st);
 int rt_launch_resolve_rays(const ExactScene& es, int n, const double* S, const double* E,
                            const int32_t* cnt, const int32_t* list, bool anyhit,
                            int32_t* hit, double* tuv, double* point, uint8_t* occ,
                            int32_t* ovf, int* counters, hipStream_t st);
-int rt_launch_overflow_primary(const ExactScene& es, int W, int H, double tan_half, int y0,
+int rt_launch_overflow_primary(const ExactScene& es, int W, int H, double tan_half, const RowMap& rows,
                                const int32_t* ovf, const int* counters,
                                int32_t* hit, double* tuv, hipStream_t st);
 int rt_launch_overflow_rays(const ExactScene& es, const double* S, const double* E,
@@ -219,7 +253,8 @@ struct ShadeArgs {
     int num_mats;
     const DevFrame* frame;
     int num_lights;
-    int W, H, y0, y1;
+    int W, H;
+    RowMap rows;
     double tan_half;
     const int32_t* hit;       // per pixel (band-local)
     const double* tuv;
@@ -230,5 +265,5 @@ struct ShadeArgs {
 };
 int rt_launch_shadow_setup(const ShadeArgs& a, hipStream_t st);
 int rt_launch_shade_final(const ShadeArgs& a, hipStream_t st);
-int rt_launch_place_rows(const uint8_t* rgb8, int W, int H, int y0, int y1, uint8_t* screen,
+int rt_launch_place_rows(const uint8_t* rgb8, int W, int H, const RowMap& rows, uint8_t* screen,
                          hipStream_t st);

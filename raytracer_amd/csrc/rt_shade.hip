@@ -39,7 +39,7 @@ __device__ __forceinline__ bool norm3(double res[3], const double a[3])
 // driver.c:121-133 + triangle_intersection.cu:185-187
 __device__ __forceinline__ void hit_point(const ShadeArgs& a, long p, double point[3])
 {
-    const int py = a.y0 + (int)(p / a.W), px = (int)(p % a.W);
+    const int py = a.rows.image_row((int)(p / a.W)), px = (int)(p % a.W);
     const double S[3] = {0, 0, 0};
     const double E[3] = {(double)(px - a.W / 2), (double)(py - a.H / 2),
                          (double)(a.W / 2) / a.tan_half};
@@ -99,7 +99,7 @@ __device__ __forceinline__ void light_geom(const DevFrame& f, int l, const doubl
 
 __global__ void __launch_bounds__(RT_WG) k_shadow_setup(const ShadeArgs a)
 {
-    const long npix = (long)a.W * (a.y1 - a.y0);
+    const long npix = (long)a.W * a.rows.rows;
     const long p = (long)blockIdx.x * RT_WG + threadIdx.x;
     if (p >= npix) return;
     const DevFrame& f = *a.frame;
@@ -150,7 +150,7 @@ __device__ __forceinline__ void tex_rgb(const ShadeArgs& a, int tex, int tri, do
 
 __global__ void __launch_bounds__(RT_WG) k_shade_final(const ShadeArgs a)
 {
-    const long npix = (long)a.W * (a.y1 - a.y0);
+    const long npix = (long)a.W * a.rows.rows;
     const long p = (long)blockIdx.x * RT_WG + threadIdx.x;
     if (p >= npix) return;
     const DevFrame& f = *a.frame;
@@ -229,14 +229,14 @@ __global__ void __launch_bounds__(RT_WG) k_shade_final(const ShadeArgs a)
 
 // driver.c:186-190: pixel (x_pix, y_pix) lands on screen row H - y_pix; y_pix = 0 is off-screen.
 __global__ void __launch_bounds__(RT_WG)
-k_place_rows(const uint8_t* __restrict__ rgb8, int W, int H, int y0, int y1,
+k_place_rows(const uint8_t* __restrict__ rgb8, int W, int H, RowMap rows,
              uint8_t* __restrict__ screen)
 {
-    const long n = (long)W * (y1 - y0) * 3;
+    const long n = (long)W * rows.rows * 3;
     const long i = (long)blockIdx.x * RT_WG + threadIdx.x;
     if (i >= n) return;
     const long row = i / ((long)W * 3), col = i - row * ((long)W * 3);
-    const int y_pix = y0 + (int)row;
+    const int y_pix = rows.image_row((int)row);
     if (y_pix < 1 || y_pix >= H) return;
     screen[(long)(H - y_pix) * W * 3 + col] = rgb8[i];
 }
@@ -255,7 +255,7 @@ int launched(const char* what)
 
 int rt_launch_shadow_setup(const ShadeArgs& a, hipStream_t st)
 {
-    const long npix = (long)a.W * (a.y1 - a.y0);
+    const long npix = (long)a.W * a.rows.rows;
     if (npix <= 0 || a.num_lights <= 0) return RT_OK;
     hipLaunchKernelGGL(k_shadow_setup, dim3((unsigned)((npix + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0,
                        st, a);
@@ -264,19 +264,19 @@ int rt_launch_shadow_setup(const ShadeArgs& a, hipStream_t st)
 
 int rt_launch_shade_final(const ShadeArgs& a, hipStream_t st)
 {
-    const long npix = (long)a.W * (a.y1 - a.y0);
+    const long npix = (long)a.W * a.rows.rows;
     if (npix <= 0) return RT_OK;
     hipLaunchKernelGGL(k_shade_final, dim3((unsigned)((npix + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0,
                        st, a);
     return launched("shade_final");
 }
 
-int rt_launch_place_rows(const uint8_t* rgb8, int W, int H, int y0, int y1, uint8_t* screen,
+int rt_launch_place_rows(const uint8_t* rgb8, int W, int H, const RowMap& rows, uint8_t* screen,
                          hipStream_t st)
 {
-    const long n = (long)W * (y1 - y0) * 3;
+    const long n = (long)W * rows.rows * 3;
     if (n <= 0) return RT_OK;
     hipLaunchKernelGGL(k_place_rows, dim3((unsigned)((n + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0, st,
-                       rgb8, W, H, y0, y1, screen);
+                       rgb8, W, H, rows, screen);
     return launched("place_rows");
 }

@@ -222,23 +222,32 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep(const SweepArgs A
 
 // Survivors of an any-hit range: rays that are neither certainly occluded nor unused.
 // `in` == nullptr means "all rays 0..n-1".  Each wave reserves one contiguous block of the
-// output, so rays that shared a wave stay together.
+// output, so rays that shared a wave stay together.  blockIdx.y = ray set (see SweepArgs).
 __global__ void __launch_bounds__(RT_WG)
-k_compact(const int32_t* __restrict__ cnt, const int32_t* __restrict__ in, int n,
-          int32_t* __restrict__ out, int* __restrict__ out_count)
+k_compact(const int32_t* __restrict__ cnt, const int32_t* __restrict__ in,
+          const int* __restrict__ in_counts, int n, long stride, int32_t* __restrict__ out,
+          int* __restrict__ out_counts)
 {
-    const long j = (long)blockIdx.x * RT_WG + threadIdx.x;
-    int id = -1;
-    if (j < n) {
-        id = in ? in[j] : (int)j;
-        if (cnt[id] & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) id = -1;
+    const long set = blockIdx.y;
+    cnt += set * stride;
+    out += set * stride;
+    if (in) {
+        in += set * stride;
+        if (in_counts) n = in_counts[set];
     }
-    const unsigned long long m = __ballot(id >= 0);
     const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0 && m) base = atomicAdd(out_count, __popcll(m));
-    base = __shfl(base, 0);
-    if (id >= 0) out[base + __popcll(m & ((1ull << lane) - 1))] = id;
+    for (long j = (long)blockIdx.x * RT_WG + threadIdx.x; j - lane < n; j += (long)gridDim.x * RT_WG) {
+        int id = -1;
+        if (j < n) {
+            id = in ? in[j] : (int)j;
+            if (cnt[id] & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) id = -1;
+        }
+        const unsigned long long m = __ballot(id >= 0);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&out_counts[set], __popcll(m));
+        base = __shfl(base, 0);
+        if (id >= 0) out[base + __popcll(m & ((1ull << lane) - 1))] = id;
+    }
 }
 
 template <int MODE, bool ANYHIT>
@@ -289,12 +298,14 @@ int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st)
                   : launch<MODE_RAYS_LINEAR, false>(a, grid, st);
 }
 
-int rt_launch_compact(const int32_t* cnt, const int32_t* in, int n, int32_t* out, int* out_count,
-                      hipStream_t st)
+int rt_launch_compact(const int32_t* cnt, const int32_t* in, const int* in_counts, int n, int sets,
+                      long stride, int32_t* out, int* out_counts, hipStream_t st)
 {
-    if (n <= 0) return RT_OK;
-    hipLaunchKernelGGL(k_compact, dim3((n + RT_WG - 1) / RT_WG), dim3(RT_WG), 0, st, cnt, in, n, out,
-                       out_count);
+    if (n <= 0 || sets <= 0) return RT_OK;
+    long wgs = (n + RT_WG - 1) / RT_WG;
+    if (wgs > 2048) wgs = 2048;         // grid-stride: a workgroup per 256 rays costs more to dispatch than to run
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)wgs, sets), dim3(RT_WG), 0, st, cnt, in, in_counts, n,
+                       stride, out, out_counts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("compact launch failed: %s", hipGetErrorString(e));

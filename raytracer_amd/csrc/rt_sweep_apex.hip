@@ -55,7 +55,7 @@ __device__ __forceinline__ Tri2 load_tri2(const float4* p) { return {p[0], p[RT_
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void finish_raster(Book& bk, int32_t* __restrict__ list_slot, int tri,
                                               const Tri2& q, const float4* __restrict__ p,
-                                              float X, float Y, float yu, float yw)
+                                              float X, float Y, float yu)
 {
     const float4 Hh = p[2 * RT_TILE], N = p[3 * RT_TILE];
     const float margin = q.Q.w;
@@ -66,7 +66,6 @@ __device__ __forceinline__ void finish_raster(Book& bk, int32_t* __restrict__ li
     const float U = __builtin_fmaf(X, q.P.x, yu);
     const float V = __builtin_fmaf(X, Hh.x, __builtin_fmaf(Y, Hh.y, Hh.z));
     const float d = __builtin_fmaf(X, N.x, __builtin_fmaf(Y, N.y, N.z));
-    (void)yw;
     const float a = U * d, b = V * d;
     const float w = __builtin_fmaf(d, d, -a) - b;
     const float m3 = __builtin_fminf(__builtin_fminf(a, b), w);
@@ -88,9 +87,10 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_raster(const Swee
     const int tiles_x = (A.W + 16 * R - 1) / (16 * R);
     const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
     const int px0 = txi * (16 * R) + (wave & 1) * (8 * R) + (lane & 7);
-    const int py = A.y0 + tyi * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const float Y = (float)(py - A.H / 2);              // driver.c:132
-    const long slot0 = (long)(py - A.y0) * A.W + px0;   // band-local pixel number
+    const int lr = tyi * 16 + (wave >> 1) * 8 + (lane >> 3);       // local row of the call's row set
+    const float Y = (float)(A.rows.image_row(lr) - A.H / 2);        // driver.c:132
+    // ray number: local pixel, in the segment of this workgroup's triangle chunk
+    const long slot0 = (long)blockIdx.y * A.chunk_stride + (long)lr * A.W + px0;
 
     float X[R];
     Book bk[R];
@@ -98,14 +98,17 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_raster(const Swee
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int px = px0 + 8 * r;
-        valid[r] = (px < A.W) && (py < A.y1);
+        valid[r] = (px < A.W) && (lr < A.rows.rows);
         X[r] = (float)(px - A.W / 2);                   // driver.c:131
         bk[r].best = INF;
         bk[r].best_hi = valid[r] ? INF : -INF;
         bk[r].cnt = valid[r] ? 0 : RT_CNT_RETIRED;
     }
 
-    const int t_begin = A.tri_begin / RT_TILE, t_end = A.tri_end / RT_TILE;
+    // this workgroup's share of the triangle range: chunk blockIdx.y of gridDim.y
+    const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
+    const int t_begin = t_first + (int)((long)t_count * blockIdx.y / gridDim.y);
+    const int t_end = t_first + (int)((long)t_count * (blockIdx.y + 1) / gridDim.y);
     unsigned long long tiles_done = 0;
     if (t_begin < t_end) {
         stage_tile<RT_APEX_PLANES>(A.planes, A.plane_stride, t_begin, tile[0], wave, lane);
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_raster(const Swee
                 for (int r = 0; r < R; ++r)
                     if (s[r] >= 0.0f)
                         finish_raster(bk[r], A.list + (slot0 + 8 * r) * RT_LIST_K, tri0 + j, cur,
-                                      base + j, X[r], Y, yu, yw);
+                                      base + j, X[r], Y, yu);
             }
         }
         ++tiles_done;
@@ -199,13 +202,26 @@ __device__ __forceinline__ void finish_apex(Book& bk, const ApexRay& r, int32_t*
 enum { APEX_TILED = 0, APEX_INDEXED = 1 };
 
 template <int MODE, int R>
-__global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_apex(const SweepArgs A)
+__global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
 {
     __shared__ float4 tile[2][RT_APEX_PLANES][RT_TILE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+
+    // ray set (light) of this workgroup
+    const long set = blockIdx.y;
+    A.planes += set * A.light_plane_stride;
+    A.S += 3 * set * A.light_ray_stride;
+    A.E += 3 * set * A.light_ray_stride;
+    A.cnt += set * A.light_ray_stride;
+    A.list += set * A.light_ray_stride * RT_LIST_K;
+    if (MODE == APEX_INDEXED) {
+        A.active += set * A.light_ray_stride;
+        if (A.live_counts) A.n_rays = A.live_counts[set];
+        if ((long)blockIdx.x * (RT_WG * R) >= A.n_rays) return;     // grid sized for the largest set
+    }
 
     ApexRay ray[R];
     Book bk[R];
@@ -224,9 +240,9 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_apex(const SweepA
             const int tiles_x = (A.W + 16 * R - 1) / (16 * R);
             const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
             const int px = txi * (16 * R) + (wave & 1) * (8 * R) + r * 8 + (lane & 7);
-            const int py = A.y0 + tyi * 16 + (wave >> 1) * 8 + (lane >> 3);
-            valid = (px < A.W) && (py < A.y1);
-            slot[r] = valid ? (int)((long)(py - A.y0) * A.W + px) : 0;
+            const int lr = tyi * 16 + (wave >> 1) * 8 + (lane >> 3);
+            valid = (px < A.W) && (lr < A.rows.rows);
+            slot[r] = valid ? (int)((long)lr * A.W + px) : 0;
         }
         in_range[r] = valid;
         double Dx = 0, Dy = 0, Dz = 0, len = 0;
@@ -357,29 +373,51 @@ static int device_cus()
     return cus;
 }
 
-// Pixels per lane for a band of W x rows pixels: the most sharing (RT_RASTER_RPL) when that
-// still gives every CU about four workgroups, fewer for small images.
-int rt_raster_pixels_per_lane(int W, int rows)
+// Launch shape of the pixel-grid sweep.  The most sharing per lane (RT_RASTER_RPL pixels) is
+// kept as long as the image is wide enough; the machine is then filled (about five
+// workgroups per CU) by cutting the triangle range into chunks that run as separate
+// workgroups with candidate lists of their own, and only a mesh too small for that
+// (a chunk keeps at least 8 tiles) gives up pixels per lane.
+void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks)
 {
-    const int cus = device_cus();
+    const long want = 5L * device_cus();
     const long tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
+    int max_chunks = tiles / 8;
+    if (max_chunks < 1) max_chunks = 1;
+    if (max_chunks > RT_RASTER_MAX_CHUNKS) max_chunks = RT_RASTER_MAX_CHUNKS;
     int r = RT_RASTER_RPL;
-    while (r > 1 && (long)((W + 16 * r - 1) / (16 * r)) * tiles_y < 4L * cus) r /= 2;
-    return r;
+    while (r > 1 && 16 * r > W + 8 * r) r /= 2;         // no lane set mostly off the image
+    for (;;) {
+        const long wgs = (long)((W + 16 * r - 1) / (16 * r)) * tiles_y;
+        long c = (want + wgs - 1) / wgs;
+        if (c <= max_chunks || r == 1) {
+            if (c > max_chunks) c = max_chunks;
+            *pixels_per_lane = r;
+            *chunks = (int)c;
+            return;
+        }
+        r /= 2;
+    }
 }
 
 int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
 {
     int rc = check_common(a);
     if (rc) return rc;
-    if (a.W <= 0 || a.H <= 0 || a.y1 <= a.y0) {
+    if (a.W <= 0 || a.H <= 0 || a.rows.rows <= 0 || a.rows.block <= 0 || a.rows.parts <= 0) {
         rt_set_error("raster sweep: empty band");
         return RT_E_ARG;
     }
-    const int r = rt_raster_pixels_per_lane(a.W, a.y1 - a.y0);
+    int r = 1, chunks = 1;
+    rt_raster_shape(a.W, a.rows.rows, (a.tri_end - a.tri_begin) / RT_TILE, &r, &chunks);
+    if (a.chunks != chunks || (chunks > 1 && a.chunk_stride < (long)a.W * a.rows.rows)) {
+        rt_set_error("raster sweep: caller and launcher disagree on the chunk count (%d vs %d)",
+                     a.chunks, chunks);
+        return RT_E_ARG;
+    }
     const int tiles_x = (a.W + 16 * r - 1) / (16 * r);
-    const int tiles_y = (a.y1 - a.y0 + RT_TILE_H - 1) / RT_TILE_H;
-    const dim3 grid(tiles_x * tiles_y);
+    const int tiles_y = (a.rows.rows + RT_TILE_H - 1) / RT_TILE_H;
+    const dim3 grid(tiles_x * tiles_y, chunks);
     switch (r) {
     case 1: return launch(k_sweep_raster<1>, a, grid, st, "raster sweep");
     case 2: return launch(k_sweep_raster<2>, a, grid, st, "raster sweep");
@@ -393,24 +431,27 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
     return RT_E_ARG;
 }
 
-// Rays per lane of an any-hit launch over n rays: RT_APEX_RPL when that still gives every CU
-// about four workgroups, fewer for small batches (more workgroups, same work per pair).
+// Rays per lane of an any-hit launch over n rays: RT_APEX_RPL while that still gives every CU
+// two to three workgroups, fewer for small batches.  The work per pair is the same, but the two
+// LDS reads per triangle are shared by fewer pairs: below 4 rays per lane the loop is bound by
+// LDS bandwidth, so this is only worth it when the machine would otherwise sit idle.
 static int apex_rays_per_lane(long n)
 {
     int r = RT_APEX_RPL;
-    while (r > 1 && n / (RT_WG * r) < 4L * device_cus()) r /= 2;
+    while (r > 1 && 2 * n / (RT_WG * r) < 5L * device_cus()) r /= 2;      // 2.5 workgroups per CU
     return r;
 }
 
 template <int MODE>
 static int launch_apex(const SweepArgs& a, int r, unsigned wgs, hipStream_t st)
 {
+    const dim3 grid(wgs, a.lights > 0 ? a.lights : 1);
     switch (r) {
-    case 1: return launch(k_sweep_apex<MODE, 1>, a, dim3(wgs), st, "apex sweep");
-    case 2: return launch(k_sweep_apex<MODE, 2>, a, dim3(wgs), st, "apex sweep");
-    case 4: return launch(k_sweep_apex<MODE, 4>, a, dim3(wgs), st, "apex sweep");
+    case 1: return launch(k_sweep_apex<MODE, 1>, a, grid, st, "apex sweep");
+    case 2: return launch(k_sweep_apex<MODE, 2>, a, grid, st, "apex sweep");
+    case 4: return launch(k_sweep_apex<MODE, 4>, a, grid, st, "apex sweep");
 #if RT_APEX_RPL > 4
-    case RT_APEX_RPL: return launch(k_sweep_apex<MODE, RT_APEX_RPL>, a, dim3(wgs), st, "apex sweep");
+    case RT_APEX_RPL: return launch(k_sweep_apex<MODE, RT_APEX_RPL>, a, grid, st, "apex sweep");
 #endif
     }
     rt_set_error("apex sweep: unsupported rays per lane %d", r);
@@ -427,16 +468,16 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
     }
     if (a.active) {     // indexed: n_rays entries of `active` name the rays
         if (a.n_rays <= 0) return RT_OK;
-        const int r = apex_rays_per_lane(a.n_rays);
+        const int r = apex_rays_per_lane((long)a.n_rays * (a.lights > 0 ? a.lights : 1));
         const int per_wg = RT_WG * r;
         return launch_apex<APEX_INDEXED>(a, r, (unsigned)((a.n_rays + per_wg - 1) / per_wg), st);
     }
-    if (a.W <= 0 || a.y1 <= a.y0) {
+    if (a.W <= 0 || a.rows.rows <= 0) {
         rt_set_error("apex sweep: empty band");
         return RT_E_ARG;
     }
-    const int r = apex_rays_per_lane((long)a.W * (a.y1 - a.y0));
+    const int r = apex_rays_per_lane((long)a.W * a.rows.rows * (a.lights > 0 ? a.lights : 1));
     const int tiles_x = (a.W + 16 * r - 1) / (16 * r);
-    const int tiles_y = (a.y1 - a.y0 + RT_TILE_H - 1) / RT_TILE_H;
+    const int tiles_y = (a.rows.rows + RT_TILE_H - 1) / RT_TILE_H;
     return launch_apex<APEX_TILED>(a, r, (unsigned)(tiles_x * tiles_y), st);
 }

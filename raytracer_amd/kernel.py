@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import RtFrame, RtProfile, check
+from ._lib import RtFrame, RtProfile, RtRows, check
 from .scenes import Mesh
 
 
@@ -98,6 +98,26 @@ def band(H: int, nranks: int, rank: int) -> tuple[int, int]:
     y0, y1 = C.c_int(), C.c_int()
     check(_lib.load().rt_band(H, nranks, rank, C.byref(y0), C.byref(y1)), "rt_band")
     return y0.value, y1.value
+
+
+def rows_part(H: int, parts: int = 1, part: int = 0, block: int = 16, y0: int = 0,
+              y1: int | None = None) -> RtRows:
+    """Row set `part` of `parts` of the rows [y0,y1), interleaved in blocks of `block` rows
+    (rt_rows in include/rt_amd.h).  parts = 1 is the contiguous band."""
+    return RtRows(y0, H if y1 is None else y1, block, parts, part)
+
+
+def rows_count(r: RtRows) -> int:
+    n = _lib.load().rt_rows_count(C.byref(r))
+    check(min(n, 0), "rt_rows_count")
+    return n
+
+
+def rows_image_rows(r: RtRows) -> np.ndarray:
+    """Image row of every local row of the set, ascending."""
+    n = rows_count(r)
+    lr = np.arange(n)
+    return r.y0 + ((lr // r.block) * r.parts + r.part) * r.block + lr % r.block
 
 
 # ------------------------------------------------------------------ batched API
@@ -210,11 +230,13 @@ class Scene:
         return occ
 
     def render_rows(self, frame: RtFrame, W: int, H: int, tan_half: float, y0: int = 0,
-                    y1: int | None = None, want=("hit", "tuv", "argb", "rgb8"), out=None):
-        """driver.c:126-193 for rows [y0,y1).  Returns a dict of device tensors."""
+                    y1: int | None = None, want=("hit", "tuv", "argb", "rgb8"), out=None,
+                    rows_set: RtRows | None = None):
+        """driver.c:126-193 for rows [y0,y1), or for an interleaved row set (rows_part).
+        Returns a dict of device tensors indexed by local row."""
         t = self.torch
         y1 = H if y1 is None else y1
-        rows = y1 - y0
+        rows = y1 - y0 if rows_set is None else rows_count(rows_set)
         o = {} if out is None else out
         if "hit" in want and "hit" not in o:
             o["hit"] = self._empty((rows, W), t.int32)
@@ -225,16 +247,26 @@ class Scene:
         if "rgb8" in want and "rgb8" not in o:
             o["rgb8"] = self._empty((rows, W, 3), t.uint8)
         ptr = lambda k: o[k].data_ptr() if k in o else None
-        check(self.lib.rt_render_rows(self.h, C.byref(frame), W, H, float(tan_half), y0, y1,
-                                      ptr("hit"), ptr("tuv"), ptr("argb"), ptr("rgb8")),
-              "rt_render_rows")
+        if rows_set is None:
+            check(self.lib.rt_render_rows(self.h, C.byref(frame), W, H, float(tan_half), y0, y1,
+                                          ptr("hit"), ptr("tuv"), ptr("argb"), ptr("rgb8")),
+                  "rt_render_rows")
+        elif rows > 0:
+            check(self.lib.rt_render_rows_part(self.h, C.byref(frame), W, H, float(tan_half),
+                                               C.byref(rows_set), ptr("hit"), ptr("tuv"), ptr("argb"),
+                                               ptr("rgb8")), "rt_render_rows_part")
         return o
 
-    def place_rows(self, rgb8, W: int, H: int, y0: int, y1: int, screen=None):
+    def place_rows(self, rgb8, W: int, H: int, y0: int = 0, y1: int = 0, screen=None,
+                   rows_set: RtRows | None = None):
         t = self.torch
         if screen is None:
             screen = t.zeros((H, W, 3), dtype=t.uint8, device=self.device)
-        check(self.lib.rt_place_rows(rgb8.data_ptr(), W, H, y0, y1, screen.data_ptr()), "rt_place_rows")
+        if rows_set is None:
+            check(self.lib.rt_place_rows(rgb8.data_ptr(), W, H, y0, y1, screen.data_ptr()), "rt_place_rows")
+        else:
+            check(self.lib.rt_place_rows_part(rgb8.data_ptr(), W, H, C.byref(rows_set), screen.data_ptr()),
+                  "rt_place_rows_part")
         return screen
 
 

@@ -1,8 +1,13 @@
-"""Row-band sharding of one frame across ranks (one process per GPU).
+"""Row sharding of one frame across ranks (one process per GPU).
 
-Pixels are independent, so each rank renders a contiguous band of rows against its own full
-copy of the mesh and the only exchange is the gather of the finished 8-bit bands to rank 0
-(RCCL over xGMI when the process group is "nccl"; the same code runs on "gloo" for CPU tests).
+Pixels are independent, so each rank renders its rows against its own full copy of the mesh
+and the only exchange is the gather of the finished 8-bit rows to rank 0 (RCCL over xGMI when
+the process group is "nccl"; the same code runs on "gloo" for CPU tests).
+
+Two ways to cut the image: contiguous bands (band_rows, the split of rt_band) and interleaved
+parts (part_rows: blocks of 16 rows dealt round-robin).  The cost of a row is uneven -- the
+shadow rays of a region cost what its occluders' positions in the triangle list dictate -- so
+interleaving is what keeps the ranks level; bench.py uses it.
 """
 from __future__ import annotations
 
@@ -43,6 +48,27 @@ def assemble_rows(gathered, H: int, world: int):
         y0, y1 = band_rows(H, world, r)
         parts.append(gathered[r][: y1 - y0])
     return torch.cat(parts, 0)
+
+
+def part_rows(H: int, world: int, rank: int, block: int = 16):
+    """Interleaved row set of `rank`: blocks rank, rank + world, ... of `block` rows."""
+    return kernel.rows_part(H, world, rank, block)
+
+
+def max_part_rows(H: int, world: int, block: int = 16) -> int:
+    return kernel.rows_count(part_rows(H, world, 0, block))      # part 0 is never the shortest
+
+
+def assemble_parts(gathered, H: int, world: int, block: int = 16):
+    """Scatters the valid rows of every rank's padded part back into image order: [H, W, 3]."""
+    import torch
+
+    out = torch.empty((H,) + tuple(gathered[0].shape[1:]), dtype=gathered[0].dtype,
+                      device=gathered[0].device)
+    for r in range(world):
+        rows = kernel.rows_image_rows(part_rows(H, world, r, block))
+        out[torch.as_tensor(rows, device=out.device)] = gathered[r][: len(rows)]
+    return out
 
 
 def place_rows_host(rgb8_rows: np.ndarray) -> np.ndarray:

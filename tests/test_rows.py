@@ -1,0 +1,46 @@
+"""Row sets (rt_rows): interleaved parts cover every row exactly once, in ascending order, and
+the contiguous band is the parts = 1 case.  Host-only: no GPU needed."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracer_amd import _lib, kernel, parallel
+
+
+@pytest.mark.parametrize("H,parts,block", [(2160, 8, 16), (480, 3, 16), (37, 4, 5), (16, 8, 16), (1, 1, 16),
+                                           (100, 7, 1), (2160, 1, 16)])
+def test_parts_partition_the_image(H, parts, block):
+    seen = []
+    for p in range(parts):
+        r = kernel.rows_part(H, parts, p, block)
+        rows = kernel.rows_image_rows(r)
+        assert len(rows) == kernel.rows_count(r)
+        assert np.all(np.diff(rows) > 0)
+        lib = _lib.load()
+        for lr in (0, len(rows) // 2, len(rows) - 1):
+            if len(rows):
+                assert lib.rt_rows_image_row(C.byref(r), lr) == rows[lr]
+        seen.append(rows)
+    allrows = np.sort(np.concatenate(seen))
+    assert np.array_equal(allrows, np.arange(H))
+    # part 0 is never shorter than any other
+    assert all(len(s) <= len(seen[0]) for s in seen)
+    assert parallel.max_part_rows(H, parts, block) == len(seen[0])
+
+
+def test_sub_range_and_band():
+    r = kernel.rows_part(100, 3, 1, 8, y0=10, y1=75)
+    rows = kernel.rows_image_rows(r)
+    assert rows[0] == 18 and rows.max() < 75 and rows.min() >= 10
+    band = kernel.rows_part(100, 1, 0, 25, y0=50, y1=75)
+    assert np.array_equal(kernel.rows_image_rows(band), np.arange(50, 75))
+
+
+@pytest.mark.parametrize("bad", [dict(block=0), dict(parts=0), dict(part=3, parts=3), dict(part=-1)])
+def test_bad_row_sets_are_rejected(bad):
+    kw = dict(parts=2, part=0, block=16)
+    kw.update(bad)
+    r = kernel.rows_part(64, kw["parts"], kw["part"], kw["block"])
+    assert _lib.load().rt_rows_count(C.byref(r)) < 0
+    assert b"row set" in _lib.load().rt_last_error()
