@@ -106,6 +106,12 @@ def main() -> None:
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the gather even with one rank")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: functional rehearsal of the multi-rank path with several ranks on one "
+                         "GPU (the gather goes through host copies); not a measurement")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed steps rank 0 renders the whole frame alone and compares it "
+                         "with the assembled screen")
     args = ap.parse_args()
 
     import torch
@@ -123,13 +129,18 @@ def main() -> None:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; this benchmark has no CPU path", file=sys.stderr)
         sys.exit(2)
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     kind, tris, W, H = WORKLOADS[args.workload]
     mesh = make_mesh(kind, tris)
@@ -157,7 +168,13 @@ def main() -> None:
         sc.render_rows(frames[k], W, H, TAN_HALF, want=("hit", "rgb8"), rows_set=my_rows,
                        out={"hit": out["hit"], "rgb8": out["rgb8"][:rows]})
         if use_dist:
-            if world > 1:
+            if args.backend == "gloo":
+                host = [torch.empty(out["rgb8"].shape, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+                dist.gather(out["rgb8"].cpu(), host, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        gathered[r].copy_(host[r])
+            elif world > 1:
                 parallel.gather_bands(out["rgb8"], H, world, rank, dst=0, out=gathered)   # RCCL over xGMI
             else:
                 dist.gather(out["rgb8"], gathered, dst=0)
@@ -168,6 +185,7 @@ def main() -> None:
             sc.place_rows(out["rgb8"], W, H, screen=screen, rows_set=my_rows)
 
     def fence():
+        torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -226,7 +244,9 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": args.workload, "mesh": mesh.name, "triangles": mesh.num_tris,
                        "width": W, "height": H, "lights": frame.num_lights,
-                       "sharding": f"{world} interleaved row parts (16-row blocks), RCCL gather to rank 0" if world > 1 else "single GPU"},
+                       "sharding": (f"{world} interleaved row parts (16-row blocks), "
+                                    f"{'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} gather to rank 0")
+                       if world > 1 else "single GPU"},
             "frames_per_s": steps / wall,
             "primary_mrays_per_s": rays_p / (wall / steps) / 1e6,
             "rays_per_frame": {"primary": rays_p, "shadow": rays_s},
@@ -255,6 +275,12 @@ def main() -> None:
                                  "shadow_rays_per_lane": spl.value, "shadow_flop_per_test": f_shadow.value},
             },
         }
+        if args.verify:
+            k = (step_no[0] - 1) % len(frames)
+            sc.transform(obmats[k])
+            alone = sc.render_rows(frames[k], W, H, TAN_HALF, want=("rgb8",))["rgb8"]
+            res["verify"] = {"screen_equals_single_rank_render":
+                             bool(torch.equal(sc.place_rows(alone, W, H, 0, H), screen))}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(mesh, frame, W, H, args.cpu_budget)
         print(json.dumps(res), flush=True)

@@ -1,0 +1,37 @@
+"""Rehearsal of bench.py's multi-rank path on one GPU: two ranks share the card, the gather
+runs on gloo through host copies, and rank 0 checks the assembled screen against a
+single-rank render of the same frame.  (RCCL refuses two ranks on one device, so the nccl
+gather itself is exercised with one rank by --force-dist.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(cmd):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_on_one_gpu_assemble_the_single_rank_frame():
+    d = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", "29547", "bench.py", "--gpus", "2",
+                "--steps", "1", "--warmup", "0", "--workload", "teapot_class_480p", "--backend", "gloo",
+                "--verify", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["verify"]["screen_equals_single_rank_render"] is True
+    assert d["rays_per_frame"]["primary"] == 640 * 480
+
+
+def test_rccl_gather_with_one_rank():
+    d = _bench([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--workload",
+                "teapot_class_480p", "--force-dist", "--verify", "--no-cpu-baseline"])
+    assert d["verify"]["screen_equals_single_rank_render"] is True
