@@ -374,13 +374,17 @@ static int device_cus()
 }
 
 // Launch shape of the pixel-grid sweep.  The most sharing per lane (RT_RASTER_RPL pixels) is
-// kept as long as the image is wide enough; the machine is then filled (about five
-// workgroups per CU) by cutting the triangle range into chunks that run as separate
-// workgroups with candidate lists of their own, and only a mesh too small for that
-// (a chunk keeps at least 8 tiles) gives up pixels per lane.
+// kept as long as the image is wide enough.  Every workgroup of a launch takes the same time,
+// so the machine drains in rounds and the last, partly filled round is wasted time; cutting the
+// triangle range into chunks that run as separate workgroups (with candidate lists of their
+// own) makes the rounds shorter and fills small bands.  Measured on the 1 M-triangle soup:
+// 8 chunks instead of 1 take 6 % off a 3840x2160 sweep and 33 % off a 3840x270 one, at the
+// price of three times as many candidates for the exact pass (less pruning across chunks).
+// A chunk keeps at least 8 tiles; a mesh too small to fill the machine that way gives up
+// pixels per lane instead.
 void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks)
 {
-    const long want = 5L * device_cus();
+    const long slots = 5L * device_cus();           // resident workgroups
     const long tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
     int max_chunks = tiles / 8;
     if (max_chunks < 1) max_chunks = 1;
@@ -389,9 +393,10 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     while (r > 1 && 16 * r > W + 8 * r) r /= 2;         // no lane set mostly off the image
     for (;;) {
         const long wgs = (long)((W + 16 * r - 1) / (16 * r)) * tiles_y;
-        long c = (want + wgs - 1) / wgs;
-        if (c <= max_chunks || r == 1) {
+        if (wgs * max_chunks >= slots || r == 1) {
+            long c = (32 * slots + wgs - 1) / wgs;      // about 32 rounds are fine-grained enough
             if (c > max_chunks) c = max_chunks;
+            if (c < 1) c = 1;
             *pixels_per_lane = r;
             *chunks = (int)c;
             return;
