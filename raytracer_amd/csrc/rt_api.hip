@@ -631,9 +631,12 @@ extern "C" int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int
 // the shadow rays of several lights, stride rays apart); later ranges run indexed over the
 // survivor lists.  launch(a) starts one range for all sets.
 template <class Launch>
-static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride, Launch&& launch)
+static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride, bool zero_counts,
+                         Launch&& launch)
 {
     hipStream_t st = rt_g().stream;
+    // the apex sweep keeps its per-ray counts in cnt[] from the start (atomic updates)
+    if (zero_counts) RT_HIP(hipMemsetAsync(a.cnt, 0, sizeof(int32_t) * (size_t)stride * sets, st));
     const int np = sc->num_tris_padded;
     RT_ARG(sets >= 1 && sets <= RT_APEX_SETS, "too many ray sets for one launch");
     RT_TRY(sc->ws_act0.reserve(sizeof(int32_t) * (size_t)stride * sets));
@@ -641,7 +644,9 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
     RT_TRY(sc->ws_live.reserve(sizeof(int) * 2 * RT_APEX_SETS));
     int32_t* act[2] = {sc->ws_act0.as<int32_t>(), sc->ws_act1.as<int32_t>()};
     int* live_dev[2] = {sc->ws_live.as<int>(), sc->ws_live.as<int>() + RT_APEX_SETS};
-    int first = np / 64;
+    static const double growth = getenv("RT_AMD_RANGE_GROWTH") ? atof(getenv("RT_AMD_RANGE_GROWTH")) : 1.5;
+    static const int first_div = getenv("RT_AMD_RANGE_FIRST") ? atoi(getenv("RT_AMD_RANGE_FIRST")) : 64;
+    int first = np / first_div;
     first = ((first + RT_TILE - 1) / RT_TILE) * RT_TILE;
     if (first < 16 * RT_TILE) first = 16 * RT_TILE;
     // a sweep of a few milliseconds is not worth the compaction round trips
@@ -675,7 +680,7 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
         for (int k = 0; k < sets; ++k) live = counts[k] > live ? counts[k] : live;
         cur ^= 1;
         indexed = true;
-        len *= 2;
+        len = (int)(len * growth + RT_TILE - 1) / RT_TILE * RT_TILE;
     }
     return RT_OK;
 }
@@ -721,7 +726,8 @@ static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E
         RT_TRY(timed_sweep([&] { return rt_launch_sweep_rays(a, false, st); }, false,
                            wgs * RT_RAYS_PER_WG * (uint64_t)np, a.tests));
     } else {
-        RT_TRY(anyhit_ranges(sc, a, n, 1, n, [&](const SweepArgs& r) { return rt_launch_sweep_rays(r, true, st); }));
+        RT_TRY(anyhit_ranges(sc, a, n, 1, n, false,
+                             [&](const SweepArgs& r) { return rt_launch_sweep_rays(r, true, st); }));
     }
     return resolve_rays(sc, n, S, E, anyhit, hit, tuv, point, occ);
 }
@@ -751,7 +757,7 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows,
         a.cnt = sc->ws_cnt.as<int32_t>() + npix * (size_t)l0;
         a.list = sc->ws_list.as<int32_t>() + npix * (size_t)l0 * RT_LIST_K;
         a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
-        RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix,
+        RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true,
                              [&](const SweepArgs& r) { return rt_launch_sweep_apex(r, st); }));
     }
     return resolve_rays(sc, (int)(npix * (size_t)L), S, E, true, nullptr, nullptr, nullptr, occ);

@@ -177,13 +177,47 @@ struct ApexRay {
     float len;          // |apex - S|: ray parameter of the apex
 };
 
-__device__ __forceinline__ void finish_apex(Book& bk, const ApexRay& r, int32_t* __restrict__ list_slot,
+// candidate() for an any-hit sweep whose triangle range is shared by several workgroups per
+// ray: the candidate count and the occluded flag of a ray live in global memory only and are
+// updated atomically.  The order of a ray's list entries is then arbitrary, which an any-hit
+// query does not care about (triangle_intersection.cu:169 asks for any dist > 0).
+__device__ __forceinline__ void candidate_shared(Book& r, int32_t* __restrict__ cnt_slot,
+                                                 int32_t* __restrict__ list_slot, int tri, float a,
+                                                 float b, float w, float d, float T, float t0,
+                                                 float margin, float en, float eT)
+{
+    if (r.best_hi == -INF) return;
+    const float ad = __builtin_fabsf(d);
+    const float den = ad - en;
+    bool certain = false;
+    if (den > 0.0f) {
+        const float q = T / d;
+        const float t = t0 + q;
+        const float terr = (eT + __builtin_fabsf(q) * en) / den * 1.000001f +
+                           U22 * (__builtin_fabsf(t0) + __builtin_fabsf(q));
+        if (!(t >= -terr)) return;
+        certain = (__builtin_fminf(__builtin_fminf(a, b), w) >= margin * ad) && (t > terr);
+    }
+    if (certain) {
+        atomicOr(cnt_slot, RT_CNT_OCCLUDED);    // the list no longer matters
+        r.best_hi = -INF;
+        return;
+    }
+    const int at = atomicAdd(cnt_slot, 1) & RT_CNT_MASK;
+    if (at < RT_LIST_K) list_slot[at] = tri;
+}
+
+__device__ __forceinline__ void finish_apex(Book& bk, const ApexRay& r, int32_t* __restrict__ cnt_slot,
+                                            int32_t* __restrict__ list_slot,
                                             int tri, const Tri2& q, const float4* __restrict__ p)
 {
     const float4 Hh = p[2 * RT_TILE], N = p[3 * RT_TILE];
     const float margin = q.Q.w;
     if (margin == INF) {
-        if (bk.best_hi != -INF) push(bk, list_slot, tri);
+        if (bk.best_hi != -INF) {
+            const int at = atomicAdd(cnt_slot, 1) & RT_CNT_MASK;
+            if (at < RT_LIST_K) list_slot[at] = tri;
+        }
         return;
     }
     const float U = dot3(r.dx, r.dy, r.dz, q.P.x, q.P.y, q.P.z);
@@ -195,8 +229,8 @@ __device__ __forceinline__ void finish_apex(Book& bk, const ApexRay& r, int32_t*
     if (__builtin_fmaf(margin, __builtin_fabsf(d), m3) > 0.0f)
         // parameter from S along the unit direction: len + k/det (the reference's t times len;
         // only its sign matters for an any-hit query, triangle_intersection.cu:169)
-        candidate<true>(bk, list_slot, tri, a, b, w, d, Hh.w, r.len, margin, N.w,
-                        U22 * __builtin_fabsf(Hh.w));
+        candidate_shared(bk, cnt_slot, list_slot, tri, a, b, w, d, Hh.w, r.len, margin, N.w,
+                         U22 * __builtin_fabsf(Hh.w));
 }
 
 enum { APEX_TILED = 0, APEX_INDEXED = 1 };
@@ -257,14 +291,15 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
             if (!(Sx == Sx) || !(inv == inv) || inv > 1e300) valid = false;
             Dx *= inv; Dy *= inv; Dz *= inv;
         }
+        // the ray's count and flags live in cnt[] (zeroed by the host before the first range)
+        if (in_range[r]) {
+            const int c0 = A.cnt[slot[r]];
+            if (!valid && !(c0 & RT_CNT_RETIRED)) atomicOr(&A.cnt[slot[r]], RT_CNT_RETIRED);
+            if (c0 & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) valid = false;
+        }
         bk[r].best = INF;
         bk[r].best_hi = valid ? INF : -INF;
-        bk[r].cnt = valid ? 0 : RT_CNT_RETIRED;
-        if (A.resume && in_range[r]) {
-            // a later triangle range of the same sweep: pick up the candidate count
-            bk[r].cnt = A.cnt[slot[r]];
-            if (bk[r].cnt & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) { bk[r].best_hi = -INF; valid = false; }
-        }
+        bk[r].cnt = 0;
         // a retired ray carries a NaN direction: s is NaN and never enters the rare path
         ray[r].dx = valid ? (float)Dx : qnan;
         ray[r].dy = valid ? (float)Dy : qnan;
@@ -272,7 +307,10 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
         ray[r].len = (float)len;
     }
 
-    const int t_begin = A.tri_begin / RT_TILE, t_end = A.tri_end / RT_TILE;
+    // this workgroup's share of the triangle range: chunk blockIdx.z of gridDim.z
+    const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
+    const int t_begin = t_first + (int)((long)t_count * blockIdx.z / gridDim.z);
+    const int t_end = t_first + (int)((long)t_count * (blockIdx.z + 1) / gridDim.z);
     unsigned long long tiles_done = 0;
     if (t_begin < t_end) {
         stage_tile<RT_APEX_PLANES>(A.planes, A.plane_stride, t_begin, tile[0], wave, lane);
@@ -304,23 +342,30 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     if (s[r] >= 0.0f) {
-                        finish_apex(bk[r], ray[r], A.list + (long)slot[r] * RT_LIST_K, tri0 + j, cur, base + j);
+                        finish_apex(bk[r], ray[r], A.cnt + slot[r], A.list + (long)slot[r] * RT_LIST_K,
+                                    tri0 + j, cur, base + j);
                         if (bk[r].best_hi == -INF) ray[r].dx = qnan;
                     }
             }
         }
         ++tiles_done;
         __builtin_amdgcn_s_waitcnt(0);
-        // retire the workgroup once every ray in it is certainly occluded or unused
+        // retire the workgroup once every ray in it is certainly occluded or unused; with
+        // several chunks per ray the flag another chunk's workgroup may have set is polled
         bool done = true;
 #pragma unroll
-        for (int r = 0; r < R; ++r) done = done && (bk[r].best_hi == -INF);
+        for (int r = 0; r < R; ++r) {
+            if (gridDim.z > 1 && bk[r].best_hi != -INF &&
+                (__hip_atomic_load(&A.cnt[slot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
+                 RT_CNT_OCCLUDED)) {
+                bk[r].best_hi = -INF;
+                ray[r].dx = qnan;
+            }
+            done = done && (bk[r].best_hi == -INF);
+        }
         if (__syncthreads_and(done)) break;
     }
 
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (in_range[r]) A.cnt[slot[r]] = bk[r].cnt;
     if (A.tests && tid == 0)
         atomicAdd(A.tests, tiles_done * (unsigned long long)RT_TILE * (RT_WG * R));
 }
@@ -447,10 +492,23 @@ static int apex_rays_per_lane(long n)
     return r;
 }
 
+// Triangle chunks of an any-hit launch of `wgs` workgroups in total over `tiles` tiles: enough
+// to give the machine about 8 rounds of work, each chunk at least 8 tiles long.
+static int apex_chunks(long wgs, int tiles)
+{
+    const long slots = 5L * device_cus();
+    long c = (8 * slots + wgs - 1) / wgs;
+    if (c > tiles / 8) c = tiles / 8;
+    if (c > RT_RASTER_MAX_CHUNKS) c = RT_RASTER_MAX_CHUNKS;
+    if (const char* e = getenv("RT_AMD_APEX_CHUNKS")) c = atoi(e);
+    return c < 1 ? 1 : (int)c;
+}
+
 template <int MODE>
 static int launch_apex(const SweepArgs& a, int r, unsigned wgs, hipStream_t st)
 {
-    const dim3 grid(wgs, a.lights > 0 ? a.lights : 1);
+    const int sets = a.lights > 0 ? a.lights : 1;
+    const dim3 grid(wgs, sets, apex_chunks((long)wgs * sets, (a.tri_end - a.tri_begin) / RT_TILE));
     switch (r) {
     case 1: return launch(k_sweep_apex<MODE, 1>, a, grid, st, "apex sweep");
     case 2: return launch(k_sweep_apex<MODE, 2>, a, grid, st, "apex sweep");
