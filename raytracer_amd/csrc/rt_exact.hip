@@ -199,17 +199,24 @@ k_resolve_rays(ExactScene es, int n, const double* __restrict__ Sa, const double
     }
 }
 
-// Full fp64 sweep of one ray by one workgroup.  Thread k visits triangles k, k+256, ... in
-// ascending order with the strict '<' rule, then the 256 partial winners are merged with
-// (smaller t, then smaller index), which is what the sequential host loop would have kept.
-__device__ __forceinline__ Best full_sweep(const ExactScene& es, const double S[3], const double E[3])
+// Full fp64 sweep of triangles [begin,end) for one ray by one workgroup.  Thread k visits
+// triangles begin+k, begin+k+256, ... in ascending order with the strict '<' rule, then the 256
+// partial winners are merged with (smaller t, then smaller index), which is what the sequential
+// host loop would have kept.
+__device__ __forceinline__ bool better(double t, int i, double bt, int bi)
+{
+    return i != -1 && (bi == -1 || t < bt || (t == bt && i < bi));
+}
+
+__device__ __forceinline__ Best full_sweep(const ExactScene& es, const double S[3], const double E[3],
+                                           int begin, int end)
 {
     __shared__ double s_t[RT_WG];
     __shared__ int s_i[RT_WG];
     __shared__ double s_u[RT_WG], s_v[RT_WG];
     Best b;
     b.t = 1e50; b.idx = -1; b.u = b.v = 0;
-    for (int i = threadIdx.x; i < es.num_tris; i += RT_WG) {
+    for (int i = begin + threadIdx.x; i < end; i += RT_WG) {
         double u, v;
         const double dist = exact_tri(es, i, S, E, u, v);
         if ((dist > 0) && (dist < b.t)) { b.t = dist; b.u = u; b.v = v; b.idx = i; }
@@ -219,10 +226,7 @@ __device__ __forceinline__ Best full_sweep(const ExactScene& es, const double S[
     for (int off = RT_WG / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) {
             const int o = threadIdx.x + off;
-            const bool other_hit = s_i[o] != -1, mine_hit = s_i[threadIdx.x] != -1;
-            const bool take = other_hit && (!mine_hit || s_t[o] < s_t[threadIdx.x] ||
-                                            (s_t[o] == s_t[threadIdx.x] && s_i[o] < s_i[threadIdx.x]));
-            if (take) {
+            if (better(s_t[o], s_i[o], s_t[threadIdx.x], s_i[threadIdx.x])) {
                 s_t[threadIdx.x] = s_t[o]; s_i[threadIdx.x] = s_i[o];
                 s_u[threadIdx.x] = s_u[o]; s_v[threadIdx.x] = s_v[o];
             }
@@ -234,61 +238,111 @@ __device__ __forceinline__ Best full_sweep(const ExactScene& es, const double S[
     return b;
 }
 
-__global__ void __launch_bounds__(RT_WG)
-k_overflow_primary(ExactScene es, int W, int H, double tan_half, RowMap rows,
-                   const int32_t* __restrict__ ovf, const int* __restrict__ counters,
-                   int32_t* __restrict__ hit, double* __restrict__ tuv)
+struct Partial { double t, u, v; int idx; int pad; };
+
+// Overflowed rays: n of them (a device-side count) share a fixed grid.  With more rays than
+// workgroups each workgroup sweeps the whole mesh for its rays; with fewer, every ray is given
+// `parts` workgroups that sweep a slice of the mesh each and leave a partial winner, and
+// k_overflow_merge picks the winner.  parts is a function of (n, grid) both kernels agree on.
+constexpr int OVERFLOW_GRID = 2048;
+__device__ __forceinline__ int overflow_parts(int n)
 {
-    const int n = counters[0];
-    for (int k = blockIdx.x; k < n; k += gridDim.x) {
-        const long p = ovf[k];
-        const int py = rows.image_row((int)(p / W)), px = (int)(p % W);
-        double S[3], E[3];
-        primary_ray(W, H, tan_half, px, py, S, E);
-        const Best b = full_sweep(es, S, E);
-        if (threadIdx.x == 0) {
-            hit[p] = b.idx;
-            if (b.idx != -1 && tuv) { tuv[3 * p] = b.t; tuv[3 * p + 1] = b.u; tuv[3 * p + 2] = b.v; }
-        }
+    int parts = 1;
+    while (parts < 64 && 2 * parts * (long)n <= OVERFLOW_GRID) parts *= 2;
+    return parts;
+}
+
+struct PrimaryRays {
+    int W, H;
+    double tan_half;
+    RowMap rows;
+    __device__ void get(long p, double S[3], double E[3]) const
+    {
+        primary_ray(W, H, tan_half, (int)(p % W), rows.image_row((int)(p / W)), S, E);
+    }
+};
+struct ListedRays {
+    const double *Sa, *Ea;
+    __device__ void get(long p, double S[3], double E[3]) const
+    {
+        S[0] = Sa[3 * p]; S[1] = Sa[3 * p + 1]; S[2] = Sa[3 * p + 2];
+        E[0] = Ea[3 * p]; E[1] = Ea[3 * p + 1]; E[2] = Ea[3 * p + 2];
+    }
+};
+
+template <bool ANYHIT>
+__device__ __forceinline__ void emit(long p, const Best& b, const double S[3], const double E[3],
+                                     int32_t* __restrict__ hit, double* __restrict__ tuv,
+                                     double* __restrict__ point, uint8_t* __restrict__ occ_out)
+{
+    if (ANYHIT) {
+        occ_out[p] = b.idx != -1 ? 1 : 0;
+        return;
+    }
+    hit[p] = b.idx;
+    if (b.idx == -1) return;
+    if (tuv) { tuv[3 * p] = b.t; tuv[3 * p + 1] = b.u; tuv[3 * p + 2] = b.v; }
+    if (point) {              // triangle_intersection.cu:185-187
+        point[3 * p] = S[0] + b.t * (E[0] - S[0]);
+        point[3 * p + 1] = S[1] + b.t * (E[1] - S[1]);
+        point[3 * p + 2] = S[2] + b.t * (E[2] - S[2]);
     }
 }
 
-template <bool ANYHIT>
+template <class RAYS, bool ANYHIT>
 __global__ void __launch_bounds__(RT_WG)
-k_overflow_rays(ExactScene es, const double* __restrict__ Sa, const double* __restrict__ Ea,
-                const int32_t* __restrict__ ovf, const int* __restrict__ counters,
-                int32_t* __restrict__ hit, double* __restrict__ tuv, double* __restrict__ point,
-                uint8_t* __restrict__ occ_out)
+k_overflow(ExactScene es, RAYS rays, const int32_t* __restrict__ ovf, const int* __restrict__ counters,
+           Partial* __restrict__ part, int32_t* __restrict__ hit, double* __restrict__ tuv,
+           double* __restrict__ point, uint8_t* __restrict__ occ_out)
 {
     const int n = counters[0];
-    for (int k = blockIdx.x; k < n; k += gridDim.x) {
-        const long p = ovf[k];
-        const double S[3] = {Sa[3 * p], Sa[3 * p + 1], Sa[3 * p + 2]};
-        const double E[3] = {Ea[3 * p], Ea[3 * p + 1], Ea[3 * p + 2]};
-        const Best b = full_sweep(es, S, E);
-        if (threadIdx.x == 0) {
-            if (ANYHIT) {
-                occ_out[p] = b.idx != -1 ? 1 : 0;
-            } else {
-                hit[p] = b.idx;
-                if (b.idx != -1) {
-                    if (tuv) { tuv[3 * p] = b.t; tuv[3 * p + 1] = b.u; tuv[3 * p + 2] = b.v; }
-                    if (point) {
-                        point[3 * p] = S[0] + b.t * (E[0] - S[0]);
-                        point[3 * p + 1] = S[1] + b.t * (E[1] - S[1]);
-                        point[3 * p + 2] = S[2] + b.t * (E[2] - S[2]);
-                    }
-                }
-            }
+    const int parts = overflow_parts(n);
+    double S[3], E[3];
+    if (parts == 1) {
+        for (int k = blockIdx.x; k < n; k += gridDim.x) {
+            const long p = ovf[k];
+            rays.get(p, S, E);
+            const Best b = full_sweep(es, S, E, 0, es.num_tris);
+            if (threadIdx.x == 0) emit<ANYHIT>(p, b, S, E, hit, tuv, point, occ_out);
         }
+        return;
     }
+    const int k = blockIdx.x / parts, g = blockIdx.x % parts;
+    if (k >= n) return;
+    rays.get(ovf[k], S, E);
+    const int begin = (int)((long)es.num_tris * g / parts), end = (int)((long)es.num_tris * (g + 1) / parts);
+    const Best b = full_sweep(es, S, E, begin, end);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x].t = b.t; part[blockIdx.x].u = b.u; part[blockIdx.x].v = b.v;
+        part[blockIdx.x].idx = b.idx;
+    }
+}
+
+template <class RAYS, bool ANYHIT>
+__global__ void __launch_bounds__(RT_WG)
+k_overflow_merge(RAYS rays, const int32_t* __restrict__ ovf, const int* __restrict__ counters,
+                 const Partial* __restrict__ part, int32_t* __restrict__ hit, double* __restrict__ tuv,
+                 double* __restrict__ point, uint8_t* __restrict__ occ_out)
+{
+    const int n = counters[0];
+    const int parts = overflow_parts(n);
+    const int k = blockIdx.x * RT_WG + threadIdx.x;
+    if (parts == 1 || k >= n) return;
+    Best b;
+    b.t = 1e50; b.idx = -1; b.u = b.v = 0;
+    for (int g = 0; g < parts; ++g) {
+        const Partial q = part[k * parts + g];
+        if (better(q.t, q.idx, b.t, b.idx)) { b.t = q.t; b.u = q.u; b.v = q.v; b.idx = q.idx; }
+    }
+    const long p = ovf[k];
+    double S[3], E[3];
+    rays.get(p, S, E);
+    emit<ANYHIT>(p, b, S, E, hit, tuv, point, occ_out);
 }
 
 // intersect_all_triangles_device: one ray, triangles spread over the whole grid, partial
 // winners merged by a last single-workgroup pass.  SE = S[3],E[3]; out = {idx, t, u, v,
 // point[3]} as 7 doubles (idx stored as a double, exact for any int).
-struct Partial { double t, u, v; int idx; int pad; };
-
 __global__ void __launch_bounds__(RT_WG)
 k_single_ray_partial(ExactScene es, const double* __restrict__ SE, Partial* __restrict__ part)
 {
@@ -356,7 +410,6 @@ int launched(const char* what)
     return RT_OK;
 }
 
-constexpr int OVERFLOW_GRID = 2048;
 constexpr int SINGLE_RAY_GRID = 256;
 
 }  // namespace
@@ -388,26 +441,44 @@ int rt_launch_resolve_rays(const ExactScene& es, int n, const double* S, const d
     return launched("resolve_rays");
 }
 
+static DevBuf& overflow_partials()
+{
+    static DevBuf b;        // OVERFLOW_GRID partial winners, kept for the life of the process
+    return b;
+}
+
+template <class RAYS, bool ANYHIT>
+static int launch_overflow(const ExactScene& es, const RAYS& rays, const int32_t* ovf, const int* counters,
+                           int32_t* hit, double* tuv, double* point, uint8_t* occ, hipStream_t st)
+{
+    DevBuf& pb = overflow_partials();
+    int rc = pb.reserve(sizeof(Partial) * OVERFLOW_GRID);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_overflow<RAYS, ANYHIT>), dim3(OVERFLOW_GRID), dim3(RT_WG), 0, st, es, rays, ovf,
+                       counters, pb.as<Partial>(), hit, tuv, point, occ);
+    rc = launched("overflow");
+    if (rc) return rc;
+    // merges at most OVERFLOW_GRID / 2 rays (more rays than that take the direct path)
+    hipLaunchKernelGGL((k_overflow_merge<RAYS, ANYHIT>), dim3(OVERFLOW_GRID / 2 / RT_WG), dim3(RT_WG), 0, st,
+                       rays, ovf, counters, pb.as<Partial>(), hit, tuv, point, occ);
+    return launched("overflow_merge");
+}
+
 int rt_launch_overflow_primary(const ExactScene& es, int W, int H, double tan_half, const RowMap& rows,
                                const int32_t* ovf, const int* counters, int32_t* hit, double* tuv,
                                hipStream_t st)
 {
-    hipLaunchKernelGGL(k_overflow_primary, dim3(OVERFLOW_GRID), dim3(RT_WG), 0, st, es, W, H,
-                       tan_half, rows, ovf, counters, hit, tuv);
-    return launched("overflow_primary");
+    const PrimaryRays rays{W, H, tan_half, rows};
+    return launch_overflow<PrimaryRays, false>(es, rays, ovf, counters, hit, tuv, nullptr, nullptr, st);
 }
 
 int rt_launch_overflow_rays(const ExactScene& es, const double* S, const double* E,
                             const int32_t* ovf, const int* counters, bool anyhit, int32_t* hit,
                             double* tuv, double* point, uint8_t* occ, hipStream_t st)
 {
-    if (anyhit)
-        hipLaunchKernelGGL(k_overflow_rays<true>, dim3(OVERFLOW_GRID), dim3(RT_WG), 0, st, es, S, E,
-                           ovf, counters, hit, tuv, point, occ);
-    else
-        hipLaunchKernelGGL(k_overflow_rays<false>, dim3(OVERFLOW_GRID), dim3(RT_WG), 0, st, es, S, E,
-                           ovf, counters, hit, tuv, point, occ);
-    return launched("overflow_rays");
+    const ListedRays rays{S, E};
+    return anyhit ? launch_overflow<ListedRays, true>(es, rays, ovf, counters, hit, tuv, point, occ, st)
+                  : launch_overflow<ListedRays, false>(es, rays, ovf, counters, hit, tuv, point, occ, st);
 }
 
 // out_dev: 7 doubles followed by SINGLE_RAY_GRID Partial records of workspace.
