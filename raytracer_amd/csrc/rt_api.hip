@@ -160,7 +160,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
     if (!sc) return RT_OK;
     DevBuf* bufs[] = {&sc->ox, &sc->oy, &sc->oz, &sc->ex, &sc->ey, &sc->ez, &sc->nx, &sc->ny, &sc->nz,
                       &sc->tu, &sc->tv, &sc->iA, &sc->iB, &sc->iC, &sc->iAn, &sc->iBn, &sc->iCn,
-                      &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex,
+                      &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts,
                       &sc->scratch_max, &sc->mat_dev, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
                       &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_live};
@@ -269,6 +269,7 @@ extern "C" int rt_scene_set_triangles(rt_scene* sc, int num_tris, const int* A, 
     const size_t pb = sizeof(float4) * (size_t)sc->num_tris_padded;
     RT_TRY(sc->planes.reserve(pb * RT_PLANES));
     RT_TRY(sc->planes_apex.reserve(pb * RT_APEX_PLANES));
+    RT_TRY(sc->tri_verts.reserve(sizeof(double) * 9 * (size_t)(num_tris > 0 ? num_tris : 1)));
     RT_TRY(sc->scratch_max.reserve(16));
     sc->transformed = false;
     return RT_OK;
@@ -451,6 +452,7 @@ static ExactScene exact_of(const rt_scene* sc)
     es.x = sc->ex.as<double>(); es.y = sc->ey.as<double>(); es.z = sc->ez.as<double>();
     es.A = sc->iA.as<int>(); es.B = sc->iB.as<int>(); es.C = sc->iC.as<int>();
     es.num_tris = sc->num_tris;
+    es.tv = sc->tri_verts.as<double>();
     return es;
 }
 
@@ -1008,6 +1010,7 @@ extern "C" int intersect_all_triangles_device(double S[3], double E[3], double u
     es.x = s.mx.as<double>(); es.y = s.my.as<double>(); es.z = s.mz.as<double>();
     es.A = s.iA.as<int>(); es.B = s.iB.as<int>(); es.C = s.iC.as<int>();
     es.num_tris = num_tris;
+    es.tv = nullptr;
     if (rt_launch_single_ray(es, io, io + 8, st) != RT_OK) legacy_fail("intersect_all_triangles_device");
     double out[7];
     ok(hipMemcpyAsync(out, io + 8, sizeof out, hipMemcpyDeviceToHost, st));

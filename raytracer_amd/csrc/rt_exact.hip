@@ -62,6 +62,13 @@ __device__ __forceinline__ double exact_single(const double S[3], const double E
 __device__ __forceinline__ double exact_tri(const ExactScene& es, int i, const double S[3],
                                             const double E[3], double& u, double& v)
 {
+    if (es.tv) {
+        const double* t = es.tv + 9 * (long)i;
+        const double A[3] = {t[0], t[1], t[2]};
+        const double B[3] = {t[3], t[4], t[5]};
+        const double C[3] = {t[6], t[7], t[8]};
+        return exact_single(S, E, A, B, C, u, v);
+    }
     const int a = es.A[i], b = es.B[i], c = es.C[i];
     const double A[3] = {es.x[a], es.y[a], es.z[a]};
     const double B[3] = {es.x[b], es.y[b], es.z[b]};

@@ -108,6 +108,7 @@ struct rt_scene {
     DevBuf planes;
     // same for the apex sweeps: RT_APEX_PLANES planes, repacked for the eye and for each light
     DevBuf planes_apex;
+    DevBuf tri_verts;           // 9 doubles per triangle, eye space (see ExactScene::tv)
     DevBuf scratch_max;         // 1 float: max |coordinate| of the eye-space vertices
     DevBuf mat_dev;             // the 4x4 of the current transform
 
@@ -224,6 +225,10 @@ struct ExactScene {
     const double *x, *y, *z;
     const int *A, *B, *C;
     int num_tris;
+    // optional: the three vertices of triangle i as 9 consecutive doubles (Ax Ay Az Bx .. Cz),
+    // the same values as x[A[i]] ..., gathered once per transform so that the exact test of a
+    // candidate reads one or two cache lines instead of twelve
+    const double* tv;
 };
 int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_half, const RowMap& rows,
                               const int32_t* cnt, const int32_t* list, int chunks, long chunk_stride,

@@ -221,13 +221,17 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep(const SweepArgs A
 }
 
 // Survivors of an any-hit range: rays that are neither certainly occluded nor unused.
-// `in` == nullptr means "all rays 0..n-1".  Each wave reserves one contiguous block of the
-// output, so rays that shared a wave stay together.  blockIdx.y = ray set (see SweepArgs).
+// `in` == nullptr means "all rays 0..n-1".  blockIdx.y = ray set (see SweepArgs).  Each
+// workgroup owns one contiguous slice of the input, counts its survivors, reserves their place
+// in the output with a single atomic and writes them in input order, so rays that were
+// neighbours stay neighbours.
 __global__ void __launch_bounds__(RT_WG)
 k_compact(const int32_t* __restrict__ cnt, const int32_t* __restrict__ in,
           const int* __restrict__ in_counts, int n, long stride, int32_t* __restrict__ out,
           int* __restrict__ out_counts)
 {
+    __shared__ int s_wave[RT_WG / 64];
+    __shared__ int s_base;
     const long set = blockIdx.y;
     cnt += set * stride;
     out += set * stride;
@@ -235,18 +239,44 @@ k_compact(const int32_t* __restrict__ cnt, const int32_t* __restrict__ in,
         in += set * stride;
         if (in_counts) n = in_counts[set];
     }
-    const int lane = threadIdx.x & 63;
-    for (long j = (long)blockIdx.x * RT_WG + threadIdx.x; j - lane < n; j += (long)gridDim.x * RT_WG) {
-        int id = -1;
-        if (j < n) {
-            id = in ? in[j] : (int)j;
-            if (cnt[id] & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) id = -1;
-        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // slice of this workgroup, a multiple of the workgroup size
+    const long per = ((long)(n + gridDim.x - 1) / gridDim.x + RT_WG - 1) / RT_WG * RT_WG;
+    const long lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+    if (lo >= n) return;
+    auto survivor = [&](long j) {
+        if (j >= hi) return -1;
+        const int id = in ? in[j] : (int)j;
+        return (cnt[id] & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) ? -1 : id;
+    };
+    int mine = 0;
+    for (long j = lo + threadIdx.x; j - threadIdx.x < hi; j += RT_WG) mine += survivor(j) >= 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0) s_wave[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+#pragma unroll
+        for (int k = 0; k < RT_WG / 64; ++k) total += s_wave[k];
+        s_base = total ? atomicAdd(&out_counts[set], total) : 0;
+    }
+    __syncthreads();
+    int base = s_base;
+    for (long j = lo + threadIdx.x; j - threadIdx.x < hi; j += RT_WG) {
+        const int id = survivor(j);
         const unsigned long long m = __ballot(id >= 0);
-        int base = 0;
-        if (lane == 0 && m) base = atomicAdd(&out_counts[set], __popcll(m));
-        base = __shfl(base, 0);
-        if (id >= 0) out[base + __popcll(m & ((1ull << lane) - 1))] = id;
+        __syncthreads();                 // s_wave is reused every round
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < RT_WG / 64; ++k) {
+            before += k < wave ? s_wave[k] : 0;
+            total += s_wave[k];
+        }
+        if (id >= 0) out[base + before + __popcll(m & ((1ull << lane) - 1))] = id;
+        base += total;
     }
 }
 

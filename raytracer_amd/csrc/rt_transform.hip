@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(RT_WG)
 k_pack(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
        const int* __restrict__ iA, const int* __restrict__ iB, const int* __restrict__ iC,
        int num_tris, int num_tris_padded, const unsigned* __restrict__ max_bits,
-       float4* __restrict__ planes)
+       float4* __restrict__ planes, double* __restrict__ tri_verts)
 {
     const int i = blockIdx.x * RT_WG + threadIdx.x;
     if (i >= num_tris_padded) return;
@@ -59,8 +59,16 @@ k_pack(const double* __restrict__ x, const double* __restrict__ y, const double*
     }
     const int a = iA[i], b = iB[i], c = iC[i];
     const double ax = x[a], ay = y[a], az = z[a];
-    const double e1x = x[b] - ax, e1y = y[b] - ay, e1z = z[b] - az;
-    const double e2x = x[c] - ax, e2y = y[c] - ay, e2z = z[c] - az;
+    const double bx = x[b], by = y[b], bz = z[b];
+    const double cx = x[c], cy = y[c], cz = z[c];
+    {       // the exact pass's copy of the triangle
+        double* t = tri_verts + 9 * (long)i;
+        t[0] = ax; t[1] = ay; t[2] = az;
+        t[3] = bx; t[4] = by; t[5] = bz;
+        t[6] = cx; t[7] = cy; t[8] = cz;
+    }
+    const double e1x = bx - ax, e1y = by - ay, e1z = bz - az;
+    const double e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
     const double l1 = sqrt(e1x * e1x + e1y * e1y + e1z * e1z);
     const double l2 = sqrt(e2x * e2x + e2y * e2y + e2z * e2z);
     const double scale = 4.0 * (double)__uint_as_float(*max_bits) * 9.5367431640625e-07;  // 2^-20
@@ -200,7 +208,7 @@ int rt_launch_pack(rt_scene* sc, hipStream_t st)
     hipLaunchKernelGGL(k_pack, dim3((np + RT_WG - 1) / RT_WG), dim3(RT_WG), 0, st,
                        sc->ex.as<double>(), sc->ey.as<double>(), sc->ez.as<double>(),
                        sc->iA.as<int>(), sc->iB.as<int>(), sc->iC.as<int>(), sc->num_tris, np,
-                       sc->scratch_max.as<unsigned>(), sc->planes.as<float4>());
+                       sc->scratch_max.as<unsigned>(), sc->planes.as<float4>(), sc->tri_verts.as<double>());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("pack launch failed: %s", hipGetErrorString(e));
