@@ -19,3 +19,13 @@ def test_hard_geometry_has_no_mismatch():
     bad, rays, hits = stress_parity.run(seeds=1, rays=12000, verbose=False)
     assert rays == 6 * 4 * 12000 and hits > rays // 2
     assert bad == 0, f"{bad} of {rays} rays differ from the oracle"
+
+
+def test_hard_geometry_frames_have_no_mismatch():
+    """The same scenes through the pixel loop: pixel-grid primary sweep, the per-light shadow
+    sweeps (one light 0.05 units off a triangle, one 500 units away) and shading."""
+    import stress_parity
+    bad_hit, bad_rgb, pixels, hits = stress_parity.run_frames(seeds=1, verbose=False)
+    assert pixels == 6 * 128 * 96 and hits > 0
+    assert bad_hit == 0, f"{bad_hit} of {pixels} pixels differ from the oracle in hit or t/u/v"
+    assert bad_rgb == 0, f"{bad_rgb} of {pixels} pixels are off by more than 1/255"

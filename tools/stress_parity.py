@@ -98,6 +98,51 @@ def run(seeds, rays, verbose=True):
     return total_bad, total_rays, total_hits
 
 
+def run_frames(seeds, W=128, H=96, verbose=True):
+    """Whole frames (primary sweep on the pixel grid + the shadow sweeps of every light +
+    shading) of the same hard scenes against the oracle's pixel loop.  Beside the driver's two
+    lights each frame gets one light placed 0.05 units off a random triangle and one far away.
+    Returns (pixels with a different hit or t/u/v, pixels whose 8-bit colour is off by more
+    than 1, pixels, hit pixels)."""
+    import copy
+    bad_hit = bad_rgb = pixels = hits = 0
+    tan_half = math.tan(math.pi / 6)
+    for name, make in CASES:
+        for seed in range(seeds):
+            mesh = copy.deepcopy(make(seed))
+            scenes.center_and_scale(mesh)           # what the reference's loader does (obj_reader.c:239-289)
+            fr = kernel.driver_frame(7 * seed + 3)
+            obmat = kernel.frame_matrix(fr, "obmat")
+            X, Y, Z = O.transform(mesh, obmat)
+            rng = np.random.default_rng(seed + 77)
+            t = int(rng.integers(0, mesh.num_tris))
+            a = mesh.A[t]
+            near = np.array([X[a], Y[a], Z[a]]) + 0.05 * rng.normal(size=3)
+            extra = [near, np.array([400.0, -300.0, 250.0])]
+            for k, pos in enumerate(extra):
+                l = fr.num_lights
+                for c in range(3):
+                    fr.light_in_eye_space[l][c] = float(pos[c])
+                    fr.light_rgb[l][c] = 0.6
+                fr.light_attenuation[l][0] = 0.0
+                fr.light_attenuation[l][1] = 0.0
+                fr.light_max_dist[l] = 1e9
+                fr.num_lights = l + 1
+            sc = kernel.Scene(mesh)
+            sc.transform(obmat)
+            got = {k: v.cpu().numpy() for k, v in sc.render_rows(fr, W, H, tan_half).items()}
+            ref = O.render_rows(O.Scene(mesh, X, Y, Z), O.frame_from(fr), W, H, tan_half)
+            m = ref["hit"] >= 0
+            bh = int((got["hit"] != ref["hit"]).sum()) + int((got["tuv"][m] != ref["tuv"][m]).any(axis=1).sum())
+            br = int((np.abs(got["rgb8"].astype(int) - ref["rgb8"].astype(int)) > 1).any(axis=2).sum())
+            bad_hit += bh; bad_rgb += br; pixels += W * H; hits += int(m.sum())
+            if verbose:
+                print(f"{name:16s} seed {seed} frame {W}x{H} lights {fr.num_lights} hit pixels {m.mean():.2f} "
+                      f"shadow rays {ref['shadow_rays']} mismatch hit/tuv {bh} rgb8 {br}", flush=True)
+            sc.close()
+    return bad_hit, bad_rgb, pixels, hits
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=3)
@@ -106,3 +151,6 @@ if __name__ == "__main__":
     t00 = time.time()
     bad, n, h = run(a.seeds, a.rays)
     print(f"TOTAL mismatches {bad} of {n} rays ({h} hits)  ({time.time()-t00:.0f} s)")
+    bh, br, px, hp = run_frames(a.seeds)
+    print(f"FRAMES: hit/tuv mismatches {bh}, rgb8 off by more than 1: {br}, of {px} pixels ({hp} hit)  "
+          f"({time.time()-t00:.0f} s)")
