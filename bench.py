@@ -230,7 +230,7 @@ def main() -> None:
                                          C.byref(f_shadow), C.byref(chunks))
         f_exec = f_primary.value
         achieved = nominal * f_exec / F_TEST      # flops the hot loop really executes
-        traffic = measured_traffic(args.workload, f"raster-tile{tile.value}-ppl{ppl.value}") if world == 1 else None
+        traffic = measured_traffic(args.workload, f"raster-tile{tile.value}-ppl{ppl.value}-chunks{chunks.value}") if world == 1 else None
         res = {
             "metric": "Mrays/s and ray-tri tests/s (% fp32 peak) at 1/2/4/8 MI355X vs host-CPU ref",
             "value": (rays_p + rays_s) / (wall / steps) / 1e6,
