@@ -143,6 +143,14 @@ def load() -> C.CDLL:
         raise RtError(
             f"{LIB_PATH} is missing: build it with raytracer_amd/csrc/build.sh "
             "(or __graft_entry__.build()); there is no fallback path")
+    # PyTorch ships a HIP runtime of its own under the same soname as the system one this
+    # library is linked against.  Whichever is loaded first serves the whole process, and
+    # torch cannot find the GPU through the system runtime ("No HIP GPUs are available"), so
+    # torch's must come first wherever torch is going to own the device buffers.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError if the library lacks a declared symbol
