@@ -166,7 +166,7 @@ def test_textured_materials():
     sc.close()
 
 
-@pytest.mark.parametrize("nl", [0, 1, 5])
+@pytest.mark.parametrize("nl", [0, 1, 5, 11])      # 11: more lights than one any-hit launch takes
 def test_light_counts(nl):
     mesh = scenes.sphere(300)
     fr = kernel.driver_frame(3)
@@ -215,12 +215,21 @@ def test_error_codes_instead_of_faults():
     fr.num_lights = 101
     assert lib.rt_render_rows(sc.h, C.byref(fr), 4, 4, TAN_HALF, 0, 4, hit.data_ptr(), None, None, None) == -1
     assert lib.rt_init(99) == -1
+    # row sets
+    fr.num_lights = 2
+    for bad in ((0, 4, 0, 2, 0), (0, 4, 2, 0, 0), (0, 4, 2, 2, 2), (0, 5, 2, 2, 0), (-1, 4, 2, 2, 0), (3, 2, 2, 2, 0)):
+        rows = _lib.RtRows(*bad)
+        assert lib.rt_render_rows_part(sc.h, C.byref(fr), 4, 4, TAN_HALF, C.byref(rows), hit.data_ptr(),
+                                       None, None, None) == -1, bad
+        assert lib.rt_place_rows_part(hit.data_ptr(), 4, 4, C.byref(rows), hit.data_ptr()) == -1, bad
     sc.close()
 
 
-def test_far_ray_origins_outside_the_error_model_still_exact_in_practice():
-    """rt_trace_rays documents a 3x-scene-radius limit on ray origins for the fp32 filter's
-    bound; rays from 10x further still match here (the bound has a ~12x safety factor)."""
+@pytest.mark.parametrize("dist", [300.0, 3.0e5])
+def test_far_ray_origins(dist):
+    """The general-position sweep works with the ray's moment (a property of its line), so the
+    filter's rounding bound does not depend on how far away the ray starts; lines that pass
+    the mesh by more than its extent are retired at set-up."""
     mesh = scenes.sphere(400)
     fr = kernel.driver_frame(0)
     X, Y, Z = O.transform(mesh, kernel.frame_matrix(fr, "obmat"))
@@ -229,7 +238,7 @@ def test_far_ray_origins_outside_the_error_model_still_exact_in_practice():
     rng = np.random.default_rng(2)
     d = rng.normal(size=(500, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)
-    S = c + 300.0 * d
+    S = c + dist * d
     E = c + rng.uniform(-6, 6, size=(500, 3))
     sc = kernel.Scene(mesh)
     sc.transform(kernel.frame_matrix(fr, "obmat"))
