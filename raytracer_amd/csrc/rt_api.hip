@@ -627,23 +627,22 @@ extern "C" int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int
     return rt_trace_primary_part(sc, W, H, tan_half, &r, hit, tuv);
 }
 
-// Any-hit sweep in triangle ranges of doubling length; the survivors are compacted between
+// Any-hit sweep in triangle ranges of growing length; the survivors are compacted between
 // ranges, so a ray's cost becomes ~ the index of its first certain occluder, not the mesh
-// size.  `a` describes the first range's launch over `sets` ray sets of n rays each (sets > 1:
-// the shadow rays of several lights, stride rays apart); later ranges run indexed over the
-// survivor lists.  launch(a) starts one range for all sets.
+// size.  Two users:
+//   * rays in general position (rt_occluded): one set of n rays, the first range sweeps them
+//     all, later ranges run indexed over the survivor list;
+//   * shadow rays of the pixel loop: `sets` lists (light x dominant axis, binned beforehand
+//     into ws_act0 with their sizes in ws_live), indexed from the first range on.
+// launch(a) starts one range for all sets.
 template <class Launch>
-static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride, bool zero_counts,
+static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride, bool binned,
                          Launch&& launch)
 {
     hipStream_t st = rt_g().stream;
-    // the apex sweep keeps its per-ray counts in cnt[] from the start (atomic updates)
-    if (zero_counts) RT_HIP(hipMemsetAsync(a.cnt, 0, sizeof(int32_t) * (size_t)stride * sets, st));
     const int np = sc->num_tris_padded;
     RT_ARG(sets >= 1 && sets <= RT_APEX_SETS, "too many ray sets for one launch");
-    RT_TRY(sc->ws_act0.reserve(sizeof(int32_t) * (size_t)stride * sets));
-    RT_TRY(sc->ws_act1.reserve(sizeof(int32_t) * (size_t)stride * sets));
-    RT_TRY(sc->ws_live.reserve(sizeof(int) * 2 * RT_APEX_SETS));
+    const int cnt_div = binned ? 3 : 1;
     int32_t* act[2] = {sc->ws_act0.as<int32_t>(), sc->ws_act1.as<int32_t>()};
     int* live_dev[2] = {sc->ws_live.as<int>(), sc->ws_live.as<int>() + RT_APEX_SETS};
     static const double growth = getenv("RT_AMD_RANGE_GROWTH") ? atof(getenv("RT_AMD_RANGE_GROWTH")) : 1.5;
@@ -651,10 +650,21 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
     int first = np / first_div;
     first = ((first + RT_TILE - 1) / RT_TILE) * RT_TILE;
     if (first < 16 * RT_TILE) first = 16 * RT_TILE;
+    int counts[RT_APEX_SETS];
+    int live = n;
+    long total = (long)n * sets;
+    auto fetch_counts = [&](const int* dev) -> int {
+        RT_HIP(hipMemcpyAsync(counts, dev, sizeof(int) * sets, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipStreamSynchronize(st));
+        live = 0; total = 0;
+        for (int k = 0; k < sets; ++k) { live = counts[k] > live ? counts[k] : live; total += counts[k]; }
+        return RT_OK;
+    };
+    if (binned) RT_TRY(fetch_counts(live_dev[0]));
     // a sweep of a few milliseconds is not worth the compaction round trips
-    if ((double)np * (double)n * sets < 1.5e10) first = np;
-    int begin = 0, len = first, live = n, cur = 0;
-    bool indexed = false;
+    if ((double)np * (double)total < 1.5e10) first = np;
+    int begin = 0, len = first, cur = 0;
+    bool indexed = binned;
     while (begin < np && live > 0) {
         int end = begin + len;
         if (end > np || np - end < len / 2) end = np;
@@ -663,27 +673,33 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
         a.active = indexed ? act[cur] : nullptr;
         a.live_counts = indexed ? live_dev[cur] : nullptr;
         a.n_rays = indexed ? live : n;          // indexed: the largest set, sizes the grid
+        a.total_rays = total;
         a.lights = sets;
         a.light_ray_stride = stride;
         RT_TRY(timed_sweep([&] { return launch(a); }, true, 0, a.tests));
         if (getenv("RT_AMD_TRACE_PASSES"))
-            fprintf(stderr, "rt_amd: any-hit range [%d,%d) over %d set(s) of at most %d rays\n", begin,
-                    end, sets, indexed ? live : n);
+            fprintf(stderr, "rt_amd: any-hit range [%d,%d) over %d set(s), %ld rays, largest %d\n", begin,
+                    end, sets, total, indexed ? live : n);
         begin = end;
         if (begin >= np) break;
-        // compact the survivors (first time from the full sets, then from the last lists)
+        // compact the survivors (from the full set the first time in the unbinned case)
         RT_HIP(hipMemsetAsync(live_dev[cur ^ 1], 0, sizeof(int) * RT_APEX_SETS, st));
         RT_TRY(rt_launch_compact(a.cnt, indexed ? act[cur] : nullptr, indexed ? live_dev[cur] : nullptr,
-                                 indexed ? live : n, sets, stride, act[cur ^ 1], live_dev[cur ^ 1], st));
-        int counts[RT_APEX_SETS];
-        RT_HIP(hipMemcpyAsync(counts, live_dev[cur ^ 1], sizeof(int) * sets, hipMemcpyDeviceToHost, st));
-        RT_HIP(hipStreamSynchronize(st));
-        live = 0;
-        for (int k = 0; k < sets; ++k) live = counts[k] > live ? counts[k] : live;
+                                 indexed ? live : n, sets, stride, cnt_div, act[cur ^ 1], live_dev[cur ^ 1],
+                                 st));
+        RT_TRY(fetch_counts(live_dev[cur ^ 1]));
         cur ^= 1;
         indexed = true;
         len = (int)(len * growth + RT_TILE - 1) / RT_TILE * RT_TILE;
     }
+    return RT_OK;
+}
+
+static int anyhit_buffers(rt_scene* sc, size_t entries)
+{
+    RT_TRY(sc->ws_act0.reserve(sizeof(int32_t) * entries));
+    RT_TRY(sc->ws_act1.reserve(sizeof(int32_t) * entries));
+    RT_TRY(sc->ws_live.reserve(sizeof(int) * 2 * RT_APEX_SETS));
     return RT_OK;
 }
 
@@ -728,6 +744,7 @@ static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E
         RT_TRY(timed_sweep([&] { return rt_launch_sweep_rays(a, false, st); }, false,
                            wgs * RT_RAYS_PER_WG * (uint64_t)np, a.tests));
     } else {
+        RT_TRY(anyhit_buffers(sc, (size_t)n));
         RT_TRY(anyhit_ranges(sc, a, n, 1, n, false,
                              [&](const SweepArgs& r) { return rt_launch_sweep_rays(r, true, st); }));
     }
@@ -735,8 +752,8 @@ static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E
 }
 
 // Shadow rays of the pixel loop: [light][pixel] rays that end at their light (k_shadow_setup).
-// Apex sweeps over planes packed relative to each light (rt_sweep_apex.hip), up to
-// RT_APEX_SETS lights per launch.
+// Apex sweeps over planes packed relative to each light (rt_sweep_apex.hip), RT_APEX_LIGHTS
+// lights per launch; the rays of a light are binned by the dominant axis of their direction.
 static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows,
                              const double* S, const double* E, uint8_t* occ)
 {
@@ -745,21 +762,27 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows,
     const int L = f->num_lights;
     RT_TRY(workspaces(sc, npix * (size_t)L));
     RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
-    for (int l0 = 0; l0 < L; l0 += RT_APEX_SETS) {
-        const int sets = L - l0 < RT_APEX_SETS ? L - l0 : RT_APEX_SETS;
-        RT_TRY(sc->planes_apex.reserve(sizeof(float4) * (size_t)sc->num_tris_padded * RT_APEX_PLANES * sets));
-        for (int k = 0; k < sets; ++k)
-            RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l0 + k], 1.0, 1.0, k, st));
+    // the apex sweep keeps its per-ray counts in cnt[] from the start (atomic updates)
+    RT_HIP(hipMemsetAsync(sc->ws_cnt.p, 0, sizeof(int32_t) * npix * (size_t)L, st));
+    for (int l0 = 0; l0 < L; l0 += RT_APEX_LIGHTS) {
+        const int lights = L - l0 < RT_APEX_LIGHTS ? L - l0 : RT_APEX_LIGHTS;
+        RT_TRY(sc->planes_apex.reserve(sizeof(float4) * (size_t)sc->num_tris_padded * RT_APEX_PLANES * lights));
+        RT_TRY(anyhit_buffers(sc, npix * 3 * (size_t)lights));
+        // |D'| <= sqrt(3) for a direction scaled to a unit dominant component
+        for (int k = 0; k < lights; ++k)
+            RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l0 + k], 1.0, 1.75, k, st));
         SweepArgs a{};
         a.planes = sc->planes_apex.as<float4>(); a.plane_stride = sc->num_tris_padded;
         a.light_plane_stride = (long)RT_APEX_PLANES * sc->num_tris_padded;
         a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
-        a.W = W; a.rows = rt_band_rows(0, nrows); a.H = 0;
         a.S = S + 3 * npix * (size_t)l0; a.E = E + 3 * npix * (size_t)l0;
         a.cnt = sc->ws_cnt.as<int32_t>() + npix * (size_t)l0;
         a.list = sc->ws_list.as<int32_t>() + npix * (size_t)l0 * RT_LIST_K;
         a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
-        RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true,
+        RT_HIP(hipMemsetAsync(sc->ws_live.p, 0, sizeof(int) * 2 * RT_APEX_SETS, st));
+        RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, sc->ws_act0.as<int32_t>(),
+                                  sc->ws_live.as<int>(), st));
+        RT_TRY(anyhit_ranges(sc, a, (int)npix, 3 * lights, (long)npix, true,
                              [&](const SweepArgs& r) { return rt_launch_sweep_apex(r, st); }));
     }
     return resolve_rays(sc, (int)(npix * (size_t)L), S, E, true, nullptr, nullptr, nullptr, occ);

@@ -64,7 +64,8 @@ constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
 #define RT_APEX_RPL 4       // rays per lane of the any-hit apex sweep
 #endif
 constexpr int RT_APEX_PLANES = 4;
-constexpr int RT_APEX_SETS = 8;     // plane sets kept side by side: lights swept per launch
+constexpr int RT_APEX_LIGHTS = 4;   // lights swept per any-hit launch (plane sets kept side by side)
+constexpr int RT_APEX_SETS = 3 * RT_APEX_LIGHTS;    // ray sets per launch: light x dominant axis
 // fp32 flops per pair in the hot loops (FMA = 2).  Pixel-grid sweep, per lane and triangle:
 // 2 row terms + 2 FMA per pixel for the two plane distances + 1 FMA per pixel for the
 // slab product.  Apex sweep: two 3-term dot products (1 mul + 2 FMA each) + 1 FMA.
@@ -193,14 +194,16 @@ struct SweepArgs {
     // outputs
     int32_t* cnt;           // per ray: candidates pushed | RT_CNT_* flags
     int32_t* list;          // RT_LIST_K candidate triangle indices per ray
-    // apex any-hit sweep only: `lights` ray sets (the shadow rays of several lights) swept by
-    // one launch, set l = blockIdx.y.  Set l has its planes light_plane_stride float4 after set
-    // l-1 and its rays, counts, lists and active entries light_ray_stride rays after; in indexed
-    // mode its number of active entries is live_counts[l] (n_rays is then only the bound the
-    // grid was sized for).
+    // apex any-hit sweep only: `lights` ray sets swept by one launch, set s = blockIdx.y =
+    // light * 3 + dominant axis of the rays' direction.  Light l has its planes
+    // light_plane_stride float4 after light l-1 and its rays, counts and lists
+    // light_ray_stride rays after; set s has its active entries at active + s *
+    // light_ray_stride, live_counts[s] of them (n_rays is the largest of those counts, what the
+    // grid is sized for; total_rays their sum).
     int lights;
     long light_ray_stride, light_plane_stride;
     const int* live_counts;
+    long total_rays;
     // pixel-grid sweep only: the triangle range is cut into `chunks` equal parts that run as
     // separate workgroups; chunk c keeps its counts and lists chunk_stride rays further on
     int chunks;
@@ -214,11 +217,15 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st);   // primary ray
 // pixels per lane (<= RT_RASTER_RPL) and the number of triangle chunks (<= RT_RASTER_MAX_CHUNKS)
 constexpr int RT_RASTER_MAX_CHUNKS = 8;
 void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks);
-int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st);     // any-hit; tiled (W > 0) or indexed
-// survivors of `sets` ray sets (stride rays apart in cnt/in/out): set l takes its n from
-// in_counts[l] when `in` is given, else all n rays; writes out_counts[l]
+int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st);     // any-hit over binned ray lists
+// shadow rays [light][pixel] -> ray-number lists per (light, dominant axis), stride entries apart
+int rt_launch_bin_rays(const double* S, const double* E, int W, int rows, int lights, long stride,
+                       int32_t* out, int* out_counts, hipStream_t st);
+// survivors of `sets` ray sets (stride entries apart in in/out; cnt of set s starts
+// (s / cnt_div) * stride rays in): set s takes its n from in_counts[s] when `in` is given, else
+// all n rays; writes out_counts[s]
 int rt_launch_compact(const int32_t* cnt, const int32_t* in, const int* in_counts, int n, int sets,
-                      long stride, int32_t* out, int* out_counts, hipStream_t st);
+                      long stride, int cnt_div, int32_t* out, int* out_counts, hipStream_t st);
 
 // rt_exact.hip
 struct ExactScene {

@@ -227,13 +227,13 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep(const SweepArgs A
 // neighbours stay neighbours.
 __global__ void __launch_bounds__(RT_WG)
 k_compact(const int32_t* __restrict__ cnt, const int32_t* __restrict__ in,
-          const int* __restrict__ in_counts, int n, long stride, int32_t* __restrict__ out,
-          int* __restrict__ out_counts)
+          const int* __restrict__ in_counts, int n, long stride, int cnt_div,
+          int32_t* __restrict__ out, int* __restrict__ out_counts)
 {
     __shared__ int s_wave[RT_WG / 64];
     __shared__ int s_base;
     const long set = blockIdx.y;
-    cnt += set * stride;
+    cnt += (set / cnt_div) * stride;
     out += set * stride;
     if (in) {
         in += set * stride;
@@ -329,13 +329,13 @@ int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st)
 }
 
 int rt_launch_compact(const int32_t* cnt, const int32_t* in, const int* in_counts, int n, int sets,
-                      long stride, int32_t* out, int* out_counts, hipStream_t st)
+                      long stride, int cnt_div, int32_t* out, int* out_counts, hipStream_t st)
 {
-    if (n <= 0 || sets <= 0) return RT_OK;
+    if (n <= 0 || sets <= 0 || cnt_div <= 0) return RT_OK;
     long wgs = (n + RT_WG - 1) / RT_WG;
     if (wgs > 2048) wgs = 2048;         // grid-stride: a workgroup per 256 rays costs more to dispatch than to run
     hipLaunchKernelGGL(k_compact, dim3((unsigned)wgs, sets), dim3(RT_WG), 0, st, cnt, in, in_counts, n,
-                       stride, out, out_counts);
+                       stride, cnt_div, out, out_counts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("compact launch failed: %s", hipGetErrorString(e));

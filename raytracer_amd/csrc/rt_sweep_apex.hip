@@ -172,10 +172,24 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_raster(const Swee
 // ------------------------------------------------------------------------------------------
 // any-hit sweep for rays that end at the apex (shadow rays of one light)
 // ------------------------------------------------------------------------------------------
+// The sign test U * W' >= -c does not change when the direction is scaled by any non-zero
+// number, so every ray uses D' = D / D_k with k its dominant axis: D'_k = 1 exactly and the
+// other two components are at most 1 in magnitude.  Rays are binned by k beforehand
+// (k_bin_rays), a workgroup handles rays of one k, and a dot product D'.p costs two FMAs
+// instead of a multiply and two:  U = fma(u, p_i, fma(v, p_j, p_k)).
 struct ApexRay {
-    float dx, dy, dz;   // unit direction S -> apex; NaN once the ray has retired
-    float len;          // |apex - S|: ray parameter of the apex
+    float u, v;         // the two minor components of D'; NaN once the ray has retired
+    float len;          // |apex - S|: ray parameter of the apex along the unit direction
+    float sig;          // D' = sig * (unit direction S -> apex), i.e. 1 / (unit direction)_k
 };
+
+template <int AX>
+__device__ __forceinline__ float dot_ax(float u, float v, const float4& p)
+{
+    if (AX == 0) return __builtin_fmaf(u, p.y, __builtin_fmaf(v, p.z, p.x));     // D' = (1, u, v)
+    if (AX == 1) return __builtin_fmaf(u, p.x, __builtin_fmaf(v, p.z, p.y));     // D' = (u, 1, v)
+    return __builtin_fmaf(u, p.x, __builtin_fmaf(v, p.y, p.z));                  // D' = (u, v, 1)
+}
 
 // candidate() for an any-hit sweep whose triangle range is shared by several workgroups per
 // ray: the candidate count and the occluded flag of a ray live in global memory only and are
@@ -207,6 +221,7 @@ __device__ __forceinline__ void candidate_shared(Book& r, int32_t* __restrict__ 
     if (at < RT_LIST_K) list_slot[at] = tri;
 }
 
+template <int AX>
 __device__ __forceinline__ void finish_apex(Book& bk, const ApexRay& r, int32_t* __restrict__ cnt_slot,
                                             int32_t* __restrict__ list_slot,
                                             int tri, const Tri2& q, const float4* __restrict__ p)
@@ -220,98 +235,33 @@ __device__ __forceinline__ void finish_apex(Book& bk, const ApexRay& r, int32_t*
         }
         return;
     }
-    const float U = dot3(r.dx, r.dy, r.dz, q.P.x, q.P.y, q.P.z);
-    const float V = dot3(r.dx, r.dy, r.dz, Hh.x, Hh.y, Hh.z);
-    const float d = dot3(r.dx, r.dy, r.dz, N.x, N.y, N.z);
+    const float U = dot_ax<AX>(r.u, r.v, q.P);
+    const float V = dot_ax<AX>(r.u, r.v, Hh);
+    const float d = dot_ax<AX>(r.u, r.v, N);
     const float a = U * d, b = V * d;
     const float w = __builtin_fmaf(d, d, -a) - b;
     const float m3 = __builtin_fminf(__builtin_fminf(a, b), w);
-    if (__builtin_fmaf(margin, __builtin_fabsf(d), m3) > 0.0f)
-        // parameter from S along the unit direction: len + k/det (the reference's t times len;
-        // only its sign matters for an any-hit query, triangle_intersection.cu:169)
-        candidate_shared(bk, cnt_slot, list_slot, tri, a, b, w, d, Hh.w, r.len, margin, N.w,
-                         U22 * __builtin_fabsf(Hh.w));
+    if (__builtin_fmaf(margin, __builtin_fabsf(d), m3) > 0.0f) {
+        // The triangle's plane meets the line apex + tau * D' at tau = k / (D'.nn).  Along the
+        // unit direction, from S: t = len + sig * tau (the reference's t times len; only its
+        // sign matters for an any-hit query, triangle_intersection.cu:169).
+        const float T = r.sig * Hh.w;
+        candidate_shared(bk, cnt_slot, list_slot, tri, a, b, w, d, T, r.len, margin, N.w,
+                         U22 * __builtin_fabsf(T));
+    }
 }
 
-enum { APEX_TILED = 0, APEX_INDEXED = 1 };
-
-template <int MODE, int R>
-__global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
+// The tile loop of one workgroup for rays of dominant axis AX.
+template <int AX, int R>
+__device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT_APEX_PLANES][RT_TILE],
+                                           ApexRay (&ray)[R], Book (&bk)[R], const int (&slot)[R],
+                                           int wave, int lane, unsigned long long& tiles_done)
 {
-    __shared__ float4 tile[2][RT_APEX_PLANES][RT_TILE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-
-    // ray set (light) of this workgroup
-    const long set = blockIdx.y;
-    A.planes += set * A.light_plane_stride;
-    A.S += 3 * set * A.light_ray_stride;
-    A.E += 3 * set * A.light_ray_stride;
-    A.cnt += set * A.light_ray_stride;
-    A.list += set * A.light_ray_stride * RT_LIST_K;
-    if (MODE == APEX_INDEXED) {
-        A.active += set * A.light_ray_stride;
-        if (A.live_counts) A.n_rays = A.live_counts[set];
-        if ((long)blockIdx.x * (RT_WG * R) >= A.n_rays) return;     // grid sized for the largest set
-    }
-
-    ApexRay ray[R];
-    Book bk[R];
-    int slot[R];
-    bool in_range[R];
     const float qnan = __builtin_nanf("");
-
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        bool valid;
-        if (MODE == APEX_INDEXED) {
-            const long j = (long)blockIdx.x * (RT_WG * R) + r * RT_WG + tid;
-            valid = j < A.n_rays;
-            slot[r] = valid ? A.active[j] : 0;
-        } else {
-            const int tiles_x = (A.W + 16 * R - 1) / (16 * R);
-            const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-            const int px = txi * (16 * R) + (wave & 1) * (8 * R) + r * 8 + (lane & 7);
-            const int lr = tyi * 16 + (wave >> 1) * 8 + (lane >> 3);
-            valid = (px < A.W) && (lr < A.rows.rows);
-            slot[r] = valid ? (int)((long)lr * A.W + px) : 0;
-        }
-        in_range[r] = valid;
-        double Dx = 0, Dy = 0, Dz = 0, len = 0;
-        if (valid) {
-            const double* s = A.S + 3 * (long)slot[r];
-            const double* e = A.E + 3 * (long)slot[r];
-            const double Sx = s[0];
-            Dx = e[0] - Sx; Dy = e[1] - s[1]; Dz = e[2] - s[2];
-            len = __builtin_sqrt(Dx * Dx + Dy * Dy + Dz * Dz);
-            const double inv = 1.0 / len;
-            // NaN origin marks an unused ray slot; a zero-length ray hits nothing
-            if (!(Sx == Sx) || !(inv == inv) || inv > 1e300) valid = false;
-            Dx *= inv; Dy *= inv; Dz *= inv;
-        }
-        // the ray's count and flags live in cnt[] (zeroed by the host before the first range)
-        if (in_range[r]) {
-            const int c0 = A.cnt[slot[r]];
-            if (!valid && !(c0 & RT_CNT_RETIRED)) atomicOr(&A.cnt[slot[r]], RT_CNT_RETIRED);
-            if (c0 & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) valid = false;
-        }
-        bk[r].best = INF;
-        bk[r].best_hi = valid ? INF : -INF;
-        bk[r].cnt = 0;
-        // a retired ray carries a NaN direction: s is NaN and never enters the rare path
-        ray[r].dx = valid ? (float)Dx : qnan;
-        ray[r].dy = valid ? (float)Dy : qnan;
-        ray[r].dz = valid ? (float)Dz : qnan;
-        ray[r].len = (float)len;
-    }
-
     // this workgroup's share of the triangle range: chunk blockIdx.z of gridDim.z
     const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
     const int t_begin = t_first + (int)((long)t_count * blockIdx.z / gridDim.z);
     const int t_end = t_first + (int)((long)t_count * (blockIdx.z + 1) / gridDim.z);
-    unsigned long long tiles_done = 0;
     if (t_begin < t_end) {
         stage_tile<RT_APEX_PLANES>(A.planes, A.plane_stride, t_begin, tile[0], wave, lane);
         __builtin_amdgcn_s_waitcnt(0);
@@ -331,8 +281,8 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
             float s[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const float U = dot3(ray[r].dx, ray[r].dy, ray[r].dz, cur.P.x, cur.P.y, cur.P.z);
-                const float Wp = dot3(ray[r].dx, ray[r].dy, ray[r].dz, cur.Q.x, cur.Q.y, cur.Q.z);
+                const float U = dot_ax<AX>(ray[r].u, ray[r].v, cur.P);
+                const float Wp = dot_ax<AX>(ray[r].u, ray[r].v, cur.Q);
                 s[r] = __builtin_fmaf(U, Wp, cur.P.w);
             }
             float mx = s[0];
@@ -342,9 +292,9 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     if (s[r] >= 0.0f) {
-                        finish_apex(bk[r], ray[r], A.cnt + slot[r], A.list + (long)slot[r] * RT_LIST_K,
-                                    tri0 + j, cur, base + j);
-                        if (bk[r].best_hi == -INF) ray[r].dx = qnan;
+                        finish_apex<AX>(bk[r], ray[r], A.cnt + slot[r], A.list + (long)slot[r] * RT_LIST_K,
+                                        tri0 + j, cur, base + j);
+                        if (bk[r].best_hi == -INF) ray[r].u = qnan;
                     }
             }
         }
@@ -359,15 +309,166 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
                 (__hip_atomic_load(&A.cnt[slot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
                  RT_CNT_OCCLUDED)) {
                 bk[r].best_hi = -INF;
-                ray[r].dx = qnan;
+                ray[r].u = qnan;
             }
             done = done && (bk[r].best_hi == -INF);
         }
         if (__syncthreads_and(done)) break;
     }
+}
+
+// blockIdx.y = ray set = light * 3 + dominant axis; blockIdx.z = triangle chunk.  Set s works on
+// the n = live_counts[s] ray numbers active[s * light_ray_stride ...]; the rays, counts and
+// lists of light l start l * light_ray_stride rays into their arrays, its planes
+// l * light_plane_stride float4 into theirs.
+template <int R>
+__global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
+{
+    __shared__ float4 tile[2][RT_APEX_PLANES][RT_TILE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    const long set = blockIdx.y, light = set / 3;
+    const int axis = (int)(set - 3 * light);
+    A.planes += light * A.light_plane_stride;
+    A.S += 3 * light * A.light_ray_stride;
+    A.E += 3 * light * A.light_ray_stride;
+    A.cnt += light * A.light_ray_stride;
+    A.list += light * A.light_ray_stride * RT_LIST_K;
+    A.active += set * A.light_ray_stride;
+    A.n_rays = A.live_counts[set];
+    if ((long)blockIdx.x * (RT_WG * R) >= A.n_rays) return;     // the grid is sized for the largest set
+
+    ApexRay ray[R];
+    Book bk[R];
+    int slot[R];
+    const float qnan = __builtin_nanf("");
+
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long j = (long)blockIdx.x * (RT_WG * R) + r * RT_WG + tid;
+        bool valid = j < A.n_rays;
+        slot[r] = valid ? A.active[j] : 0;
+        double D[3] = {0, 0, 0}, len = 0, sig = 0;
+        if (valid) {
+            const double* s = A.S + 3 * (long)slot[r];
+            const double* e = A.E + 3 * (long)slot[r];
+            D[0] = e[0] - s[0]; D[1] = e[1] - s[1]; D[2] = e[2] - s[2];
+            len = __builtin_sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
+            const double dk = axis == 0 ? D[0] : (axis == 1 ? D[1] : D[2]);
+            sig = len / dk;                         // 1 / (unit direction)_k
+            // listed rays have a finite, non-zero direction (k_bin_rays); be safe regardless
+            if (!(len > 0) || !(sig == sig) || sig > 1e300 || sig < -1e300) valid = false;
+            // the ray's count and flags live in cnt[] (zeroed by the host before the first range)
+            if (A.cnt[slot[r]] & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) valid = false;
+        }
+        const double du = (axis == 0 ? D[1] : D[0]), dv = (axis == 2 ? D[1] : D[2]);
+        const double dk = axis == 0 ? D[0] : (axis == 1 ? D[1] : D[2]);
+        bk[r].best = INF;
+        bk[r].best_hi = valid ? INF : -INF;
+        bk[r].cnt = 0;
+        // a retired ray carries a NaN direction: s is NaN and never enters the rare path
+        ray[r].u = valid ? (float)(du / dk) : qnan;
+        ray[r].v = valid ? (float)(dv / dk) : qnan;
+        ray[r].len = (float)len;
+        ray[r].sig = (float)sig;
+    }
+
+    unsigned long long tiles_done = 0;
+    switch (axis) {         // uniform over the workgroup
+    case 0: apex_tiles<0, R>(A, tile, ray, bk, slot, wave, lane, tiles_done); break;
+    case 1: apex_tiles<1, R>(A, tile, ray, bk, slot, wave, lane, tiles_done); break;
+    default: apex_tiles<2, R>(A, tile, ray, bk, slot, wave, lane, tiles_done); break;
+    }
 
     if (A.tests && tid == 0)
         atomicAdd(A.tests, tiles_done * (unsigned long long)RT_TILE * (RT_WG * R));
+}
+
+// Bins the shadow rays of every light by the dominant axis of their direction: ray numbers
+// (local pixel numbers) of set light * 3 + axis go to out[set * stride ...], their number to
+// out_counts[set].  Rays are visited in the order of the 64 x 16 pixel tiles, and every
+// workgroup writes its slice in that order, so the rays of a sweep workgroup stay neighbours on
+// the screen (they tend to retire together).  Unused slots (NaN origin) are left out.
+__global__ void __launch_bounds__(RT_WG)
+k_bin_rays(const double* __restrict__ S, const double* __restrict__ E, int W, int rows, long stride,
+           int32_t* __restrict__ out, int* __restrict__ out_counts)
+{
+    __shared__ int s_wave[RT_WG / 64][3];
+    __shared__ int s_base[3];
+    const long light = blockIdx.y;
+    S += 3 * light * stride;
+    E += 3 * light * stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles_x = (W + 63) / 64, tiles_y = (rows + 15) / 16;
+    const long total = (long)tiles_x * tiles_y * 1024;
+    const long per = ((total + gridDim.x - 1) / gridDim.x + RT_WG - 1) / RT_WG * RT_WG;
+    const long lo = per * blockIdx.x, hi = lo + per < total ? lo + per : total;
+    if (lo >= total) return;
+    auto classify = [&](long e, int& id) {          // -1 = no ray, else dominant axis
+        id = -1;
+        if (e >= hi) return -1;
+        const long t = e >> 10;
+        const int w = (int)(e & 1023), tx = (int)(t % tiles_x), ty = (int)(t / tiles_x);
+        const int px = tx * 64 + (w & 63), lr = ty * 16 + (w >> 6);
+        if (px >= W || lr >= rows) return -1;
+        id = lr * W + px;
+        const double* s = S + 3 * (long)id;
+        const double* en = E + 3 * (long)id;
+        const double sx = s[0];
+        if (!(sx == sx)) return -1;                 // unused slot
+        const double dx = fabs(en[0] - sx), dy = fabs(en[1] - s[1]), dz = fabs(en[2] - s[2]);
+        if (!(dx + dy + dz > 0) || !(dx + dy + dz < 1e300)) return -1;     // zero-length or non-finite: hits nothing
+        return dx >= dy && dx >= dz ? 0 : (dy >= dz ? 1 : 2);
+    };
+    int mine[3] = {0, 0, 0};
+    for (long e = lo + threadIdx.x; e - threadIdx.x < hi; e += RT_WG) {
+        int id;
+        const int ax = classify(e, id);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) mine[k] += ax == k;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine[k] += __shfl_xor(mine[k], off);
+        if (lane == 0) s_wave[wave][k] = mine[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int total_k = 0;
+        for (int wv = 0; wv < RT_WG / 64; ++wv) total_k += s_wave[wv][threadIdx.x];
+        s_base[threadIdx.x] = total_k ? atomicAdd(&out_counts[light * 3 + threadIdx.x], total_k) : 0;
+    }
+    __syncthreads();
+    int base[3] = {s_base[0], s_base[1], s_base[2]};
+    for (long e = lo + threadIdx.x; e - threadIdx.x < hi; e += RT_WG) {
+        int id;
+        const int ax = classify(e, id);
+        unsigned long long m[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) m[k] = __ballot(ax == k);
+        __syncthreads();                 // s_wave is reused every round
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s_wave[wave][k] = __popcll(m[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int before = 0, total_k = 0;
+#pragma unroll
+            for (int wv = 0; wv < RT_WG / 64; ++wv) {
+                before += wv < wave ? s_wave[wv][k] : 0;
+                total_k += s_wave[wv][k];
+            }
+            if (ax == k)
+                out[(light * 3 + k) * stride + base[k] + before + __popcll(m[k] & ((1ull << lane) - 1))] = id;
+            base[k] += total_k;
+        }
+    }
 }
 
 template <class K>
@@ -500,47 +601,50 @@ static int apex_chunks(long wgs, int tiles)
     long c = (8 * slots + wgs - 1) / wgs;
     if (c > tiles / 8) c = tiles / 8;
     if (c > RT_RASTER_MAX_CHUNKS) c = RT_RASTER_MAX_CHUNKS;
-    if (const char* e = getenv("RT_AMD_APEX_CHUNKS")) c = atoi(e);
     return c < 1 ? 1 : (int)c;
 }
 
-template <int MODE>
-static int launch_apex(const SweepArgs& a, int r, unsigned wgs, hipStream_t st)
+// a.lights = number of ray sets (lights * 3), a.n_rays = size of the largest set, a.total_rays =
+// rays in all sets together (both known to the host from the last compaction)
+int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
 {
-    const int sets = a.lights > 0 ? a.lights : 1;
-    const dim3 grid(wgs, sets, apex_chunks((long)wgs * sets, (a.tri_end - a.tri_begin) / RT_TILE));
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (!a.S || !a.E || !a.active || !a.live_counts || a.lights <= 0 || a.lights % 3 != 0) {
+        rt_set_error("apex sweep: needs binned ray lists (3 sets per light)");
+        return RT_E_ARG;
+    }
+    if (a.n_rays <= 0) return RT_OK;
+    const int r = apex_rays_per_lane(a.total_rays > 0 ? a.total_rays : (long)a.n_rays * a.lights);
+    const int per_wg = RT_WG * r;
+    const unsigned wgs = (unsigned)((a.n_rays + per_wg - 1) / per_wg);
+    const long all_wgs = a.total_rays > 0 ? (a.total_rays + per_wg - 1) / per_wg + a.lights : (long)wgs * a.lights;
+    const dim3 grid(wgs, a.lights, apex_chunks(all_wgs, (a.tri_end - a.tri_begin) / RT_TILE));
     switch (r) {
-    case 1: return launch(k_sweep_apex<MODE, 1>, a, grid, st, "apex sweep");
-    case 2: return launch(k_sweep_apex<MODE, 2>, a, grid, st, "apex sweep");
-    case 4: return launch(k_sweep_apex<MODE, 4>, a, grid, st, "apex sweep");
+    case 1: return launch(k_sweep_apex<1>, a, grid, st, "apex sweep");
+    case 2: return launch(k_sweep_apex<2>, a, grid, st, "apex sweep");
+    case 4: return launch(k_sweep_apex<4>, a, grid, st, "apex sweep");
 #if RT_APEX_RPL > 4
-    case RT_APEX_RPL: return launch(k_sweep_apex<MODE, RT_APEX_RPL>, a, grid, st, "apex sweep");
+    case RT_APEX_RPL: return launch(k_sweep_apex<RT_APEX_RPL>, a, grid, st, "apex sweep");
 #endif
     }
     rt_set_error("apex sweep: unsupported rays per lane %d", r);
     return RT_E_ARG;
 }
 
-int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
+int rt_launch_bin_rays(const double* S, const double* E, int W, int rows, int lights, long stride,
+                       int32_t* out, int* out_counts, hipStream_t st)
 {
-    int rc = check_common(a);
-    if (rc) return rc;
-    if (!a.S || !a.E) {
-        rt_set_error("apex sweep: null ray arrays");
-        return RT_E_ARG;
+    if (W <= 0 || rows <= 0 || lights <= 0) return RT_OK;
+    const long total = (long)((W + 63) / 64) * ((rows + 15) / 16) * 1024;
+    long wgs = (total + RT_WG - 1) / RT_WG;
+    if (wgs > 2048) wgs = 2048;
+    hipLaunchKernelGGL(k_bin_rays, dim3((unsigned)wgs, lights), dim3(RT_WG), 0, st, S, E, W, rows, stride,
+                       out, out_counts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        rt_set_error("bin_rays launch failed: %s", hipGetErrorString(e));
+        return RT_E_HIP;
     }
-    if (a.active) {     // indexed: n_rays entries of `active` name the rays
-        if (a.n_rays <= 0) return RT_OK;
-        const int r = apex_rays_per_lane((long)a.n_rays * (a.lights > 0 ? a.lights : 1));
-        const int per_wg = RT_WG * r;
-        return launch_apex<APEX_INDEXED>(a, r, (unsigned)((a.n_rays + per_wg - 1) / per_wg), st);
-    }
-    if (a.W <= 0 || a.rows.rows <= 0) {
-        rt_set_error("apex sweep: empty band");
-        return RT_E_ARG;
-    }
-    const int r = apex_rays_per_lane((long)a.W * a.rows.rows * (a.lights > 0 ? a.lights : 1));
-    const int tiles_x = (a.W + 16 * r - 1) / (16 * r);
-    const int tiles_y = (a.rows.rows + RT_TILE_H - 1) / RT_TILE_H;
-    return launch_apex<APEX_TILED>(a, r, (unsigned)(tiles_x * tiles_y), st);
+    return RT_OK;
 }
