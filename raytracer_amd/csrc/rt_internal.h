@@ -61,16 +61,16 @@ constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
 #define RT_RASTER_RPL 8     // pixels per lane of the primary (pixel-grid) sweep
 #endif
 #ifndef RT_APEX_RPL
-#define RT_APEX_RPL 4       // rays per lane of the any-hit apex sweep
+#define RT_APEX_RPL 8       // rays per lane of the any-hit apex sweep
 #endif
 constexpr int RT_APEX_PLANES = 4;
 constexpr int RT_APEX_LIGHTS = 4;   // lights swept per any-hit launch (plane sets kept side by side)
 constexpr int RT_APEX_SETS = 3 * RT_APEX_LIGHTS;    // ray sets per launch: light x dominant axis
 // fp32 flops per pair in the hot loops (FMA = 2).  Pixel-grid sweep, per lane and triangle:
 // 2 row terms + 2 FMA per pixel for the two plane distances + 1 FMA per pixel for the
-// slab product.  Apex sweep: two 3-term dot products (1 mul + 2 FMA each) + 1 FMA.
+// slab product.  Apex sweep: two dot products with a unit dominant component (2 FMA each) + 1 FMA.
 constexpr double rt_raster_flop_per_pair(int rpl) { return (2.0 * 2 + rpl * 3 * 2.0) / rpl; }
-constexpr double RT_APEX_FLOP_PER_PAIR = 12.0;
+constexpr double RT_APEX_FLOP_PER_PAIR = 10.0;
 
 // per-ray candidate counter written by the sweep: low bits = candidates pushed, plus
 constexpr int RT_CNT_OCCLUDED = 0x40000000;   // any-hit: a certain hit was found

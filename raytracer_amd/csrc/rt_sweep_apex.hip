@@ -292,7 +292,11 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     if (s[r] >= 0.0f) {
-                        finish_apex<AX>(bk[r], ray[r], A.cnt + slot[r], A.list + (long)slot[r] * RT_LIST_K,
+                        // the ray's addresses are formed here, in the rare path: hoisted out of the
+                        // loop they would cost four more registers per ray
+                        int sl = slot[r];
+                        asm volatile("" : "+v"(sl));
+                        finish_apex<AX>(bk[r], ray[r], A.cnt + sl, A.list + (long)sl * RT_LIST_K,
                                         tri0 + j, cur, base + j);
                         if (bk[r].best_hi == -INF) ray[r].u = qnan;
                     }
@@ -321,8 +325,10 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
 // the n = live_counts[s] ray numbers active[s * light_ray_stride ...]; the rays, counts and
 // lists of light l start l * light_ray_stride rays into their arrays, its planes
 // l * light_plane_stride float4 into theirs.
+// (8 rays per lane fit 4 waves per SIMD only with the rare path's temporaries spilled; measured
+// 4 % faster on the whole frame than 4 rays per lane without spills)
 template <int R>
-__global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
+__global__ void __launch_bounds__(RT_WG, R >= 8 ? 4 : RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
 {
     __shared__ float4 tile[2][RT_APEX_PLANES][RT_TILE];
 
@@ -582,14 +588,16 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
     return RT_E_ARG;
 }
 
-// Rays per lane of an any-hit launch over n rays: RT_APEX_RPL while that still gives every CU
-// two to three workgroups, fewer for small batches.  The work per pair is the same, but the two
-// LDS reads per triangle are shared by fewer pairs: below 4 rays per lane the loop is bound by
-// LDS bandwidth, so this is only worth it when the machine would otherwise sit idle.
+// Rays per lane of an any-hit launch over n rays.  The work per pair is the same for every
+// choice, but the two LDS reads per triangle and the sign-test reduction are shared by more
+// pairs with more rays per lane: 8 (at 4 waves per SIMD) is best when there are at least six
+// such workgroups per CU, 4 down to two to three workgroups per CU, and below 4 the loop is
+// bound by LDS bandwidth, which is only worth it when the machine would otherwise sit idle.
 static int apex_rays_per_lane(long n)
 {
     int r = RT_APEX_RPL;
-    while (r > 1 && 2 * n / (RT_WG * r) < 5L * device_cus()) r /= 2;      // 2.5 workgroups per CU
+    if (r >= 8 && n / (RT_WG * r) < 6L * device_cus()) r = 4;
+    while (r > 1 && r <= 4 && 2 * n / (RT_WG * r) < 5L * device_cus()) r /= 2;     // 2.5 workgroups per CU
     return r;
 }
 
