@@ -163,7 +163,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts,
                       &sc->scratch_max, &sc->mat_dev, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
-                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_live};
+                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : sc->tex_data) b.release();
     delete sc;
@@ -699,7 +699,7 @@ static int anyhit_buffers(rt_scene* sc, size_t entries)
 {
     RT_TRY(sc->ws_act0.reserve(sizeof(int32_t) * entries));
     RT_TRY(sc->ws_act1.reserve(sizeof(int32_t) * entries));
-    RT_TRY(sc->ws_live.reserve(sizeof(int) * 2 * RT_APEX_SETS));
+    RT_TRY(sc->ws_live.reserve(sizeof(int) * 3 * RT_APEX_SETS));
     return RT_OK;
 }
 
@@ -764,6 +764,11 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows,
     RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
     // the apex sweep keeps its per-ray counts in cnt[] from the start (atomic updates)
     RT_HIP(hipMemsetAsync(sc->ws_cnt.p, 0, sizeof(int32_t) * npix * (size_t)L, st));
+    static const bool use_cache = !(getenv("RT_AMD_SHADOW_CACHE") && atoi(getenv("RT_AMD_SHADOW_CACHE")) == 0);
+    if (use_cache) {
+        RT_TRY(sc->ws_occid.reserve(sizeof(int32_t) * npix * (size_t)L));
+        RT_HIP(hipMemsetAsync(sc->ws_occid.p, 0xFF, sizeof(int32_t) * npix * (size_t)L, st));     // -1 = none
+    }
     for (int l0 = 0; l0 < L; l0 += RT_APEX_LIGHTS) {
         const int lights = L - l0 < RT_APEX_LIGHTS ? L - l0 : RT_APEX_LIGHTS;
         RT_TRY(sc->planes_apex.reserve(sizeof(float4) * (size_t)sc->num_tris_padded * RT_APEX_PLANES * lights));
@@ -779,11 +784,31 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows,
         a.cnt = sc->ws_cnt.as<int32_t>() + npix * (size_t)l0;
         a.list = sc->ws_list.as<int32_t>() + npix * (size_t)l0 * RT_LIST_K;
         a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
-        RT_HIP(hipMemsetAsync(sc->ws_live.p, 0, sizeof(int) * 2 * RT_APEX_SETS, st));
-        RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, sc->ws_act0.as<int32_t>(),
-                                  sc->ws_live.as<int>(), st));
-        RT_TRY(anyhit_ranges(sc, a, (int)npix, 3 * lights, (long)npix, true,
-                             [&](const SweepArgs& r) { return rt_launch_sweep_apex(r, st); }));
+        const int sets = 3 * lights;
+        int32_t* act0 = sc->ws_act0.as<int32_t>();
+        int* live0 = sc->ws_live.as<int>();
+        auto sweep = [&](const SweepArgs& r) { return rt_launch_sweep_apex(r, st); };
+        RT_HIP(hipMemsetAsync(sc->ws_live.p, 0, sizeof(int) * 3 * RT_APEX_SETS, st));
+        if (!use_cache) {
+            RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, 0, act0, live0, st));
+            RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
+            continue;
+        }
+        // Occluder cache (k_try_cached): the rays of every 4th pixel in x and y first ...
+        RT_TRY(sc->ws_act2.reserve(sizeof(int32_t) * npix * (size_t)sets));
+        int32_t* act2 = sc->ws_act2.as<int32_t>();
+        int* live2 = live0 + 2 * RT_APEX_SETS;
+        a.occ_id = sc->ws_occid.as<int32_t>() + npix * (size_t)l0;
+        RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, 1, act0, live0, st));
+        RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, 2, act2, live2, st));
+        RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
+        // ... then every other ray tries the occluders found around it, and what is left is swept
+        RT_TRY(rt_launch_try_cached(exact_of(sc), a.S, a.E, act2, live2, sets, (int)npix, (long)npix, W,
+                                    nrows, a.cnt, a.occ_id, st));
+        RT_HIP(hipMemsetAsync(live0, 0, sizeof(int) * RT_APEX_SETS, st));
+        RT_TRY(rt_launch_compact(a.cnt, act2, live2, (int)npix, sets, (long)npix, 3, act0, live0, st));
+        a.occ_id = nullptr;
+        RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
     }
     return resolve_rays(sc, (int)(npix * (size_t)L), S, E, true, nullptr, nullptr, nullptr, occ);
 }

@@ -115,7 +115,7 @@ struct rt_scene {
 
     // per-call workspaces (grow-only)
     DevBuf ws_cnt, ws_list, ws_ovf, ws_counters;
-    DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_live;
+    DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_act2, ws_live, ws_occid;
 };
 
 struct DevMaterial {
@@ -204,6 +204,7 @@ struct SweepArgs {
     long light_ray_stride, light_plane_stride;
     const int* live_counts;
     long total_rays;
+    int32_t* occ_id;        // per ray (laid out like cnt): the triangle of its certain hit, or nullptr
     // pixel-grid sweep only: the triangle range is cut into `chunks` equal parts that run as
     // separate workgroups; chunk c keeps its counts and lists chunk_stride rays further on
     int chunks;
@@ -219,8 +220,11 @@ constexpr int RT_RASTER_MAX_CHUNKS = 8;
 void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks);
 int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st);     // any-hit over binned ray lists
 // shadow rays [light][pixel] -> ray-number lists per (light, dominant axis), stride entries apart
+// which = 0: every ray; 1: only the rays of pixels whose column and local row are multiples of
+// RT_SHADOW_SAMPLE (the sample rays of the occluder cache); 2: all the others
 int rt_launch_bin_rays(const double* S, const double* E, int W, int rows, int lights, long stride,
-                       int32_t* out, int* out_counts, hipStream_t st);
+                       int which, int32_t* out, int* out_counts, hipStream_t st);
+constexpr int RT_SHADOW_SAMPLE = 4;
 // survivors of `sets` ray sets (stride entries apart in in/out; cnt of set s starts
 // (s / cnt_div) * stride rays in): set s takes its n from in_counts[s] when `in` is given, else
 // all n rays; writes out_counts[s]
@@ -252,6 +256,12 @@ int rt_launch_overflow_rays(const ExactScene& es, const double* S, const double*
                             const int32_t* ovf, const int* counters, bool anyhit,
                             int32_t* hit, double* tuv, double* point, uint8_t* occ,
                             hipStream_t st);
+// Occluder cache: every listed ray (sets = lights x 3, laid out like the apex sweep's lists)
+// tries the triangles that occluded the sample rays around its pixel with the exact test and
+// is marked occluded in cnt[] on success.
+int rt_launch_try_cached(const ExactScene& es, const double* S, const double* E, const int32_t* lists,
+                         const int* counts, int sets, int n_max, long stride, int W, int rows,
+                         int32_t* cnt, int32_t* occ_id, hipStream_t st);
 int rt_launch_single_ray(const ExactScene& es, const double* S_E_dev, double* out_dev,
                          hipStream_t st);
 

@@ -196,7 +196,8 @@ __device__ __forceinline__ float dot_ax(float u, float v, const float4& p)
 // updated atomically.  The order of a ray's list entries is then arbitrary, which an any-hit
 // query does not care about (triangle_intersection.cu:169 asks for any dist > 0).
 __device__ __forceinline__ void candidate_shared(Book& r, int32_t* __restrict__ cnt_slot,
-                                                 int32_t* __restrict__ list_slot, int tri, float a,
+                                                 int32_t* __restrict__ list_slot,
+                                                 int32_t* __restrict__ occ_slot, int tri, float a,
                                                  float b, float w, float d, float T, float t0,
                                                  float margin, float en, float eT)
 {
@@ -214,6 +215,7 @@ __device__ __forceinline__ void candidate_shared(Book& r, int32_t* __restrict__ 
     }
     if (certain) {
         atomicOr(cnt_slot, RT_CNT_OCCLUDED);    // the list no longer matters
+        if (occ_slot) *occ_slot = tri;          // for the occluder cache (any certain occluder will do)
         r.best_hi = -INF;
         return;
     }
@@ -223,7 +225,7 @@ __device__ __forceinline__ void candidate_shared(Book& r, int32_t* __restrict__ 
 
 template <int AX>
 __device__ __forceinline__ void finish_apex(Book& bk, const ApexRay& r, int32_t* __restrict__ cnt_slot,
-                                            int32_t* __restrict__ list_slot,
+                                            int32_t* __restrict__ list_slot, int32_t* __restrict__ occ_slot,
                                             int tri, const Tri2& q, const float4* __restrict__ p)
 {
     const float4 Hh = p[2 * RT_TILE], N = p[3 * RT_TILE];
@@ -246,7 +248,7 @@ __device__ __forceinline__ void finish_apex(Book& bk, const ApexRay& r, int32_t*
         // unit direction, from S: t = len + sig * tau (the reference's t times len; only its
         // sign matters for an any-hit query, triangle_intersection.cu:169).
         const float T = r.sig * Hh.w;
-        candidate_shared(bk, cnt_slot, list_slot, tri, a, b, w, d, T, r.len, margin, N.w,
+        candidate_shared(bk, cnt_slot, list_slot, occ_slot, tri, a, b, w, d, T, r.len, margin, N.w,
                          U22 * __builtin_fabsf(T));
     }
 }
@@ -297,7 +299,7 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
                         int sl = slot[r];
                         asm volatile("" : "+v"(sl));
                         finish_apex<AX>(bk[r], ray[r], A.cnt + sl, A.list + (long)sl * RT_LIST_K,
-                                        tri0 + j, cur, base + j);
+                                        A.occ_id ? A.occ_id + sl : nullptr, tri0 + j, cur, base + j);
                         if (bk[r].best_hi == -INF) ray[r].u = qnan;
                     }
             }
@@ -343,6 +345,7 @@ __global__ void __launch_bounds__(RT_WG, R >= 8 ? 4 : RT_MIN_WAVES) k_sweep_apex
     A.E += 3 * light * A.light_ray_stride;
     A.cnt += light * A.light_ray_stride;
     A.list += light * A.light_ray_stride * RT_LIST_K;
+    if (A.occ_id) A.occ_id += light * A.light_ray_stride;
     A.active += set * A.light_ray_stride;
     A.n_rays = A.live_counts[set];
     if ((long)blockIdx.x * (RT_WG * R) >= A.n_rays) return;     // the grid is sized for the largest set
@@ -397,10 +400,11 @@ __global__ void __launch_bounds__(RT_WG, R >= 8 ? 4 : RT_MIN_WAVES) k_sweep_apex
 // (local pixel numbers) of set light * 3 + axis go to out[set * stride ...], their number to
 // out_counts[set].  Rays are visited in the order of the 64 x 16 pixel tiles, and every
 // workgroup writes its slice in that order, so the rays of a sweep workgroup stay neighbours on
-// the screen (they tend to retire together).  Unused slots (NaN origin) are left out.
+// the screen (they tend to retire together).  Unused slots (NaN origin) are left out, and
+// `which` selects all rays, the sample rays of the occluder cache, or the others.
 __global__ void __launch_bounds__(RT_WG)
 k_bin_rays(const double* __restrict__ S, const double* __restrict__ E, int W, int rows, long stride,
-           int32_t* __restrict__ out, int* __restrict__ out_counts)
+           int which, int32_t* __restrict__ out, int* __restrict__ out_counts)
 {
     __shared__ int s_wave[RT_WG / 64][3];
     __shared__ int s_base[3];
@@ -420,6 +424,10 @@ k_bin_rays(const double* __restrict__ S, const double* __restrict__ E, int W, in
         const int w = (int)(e & 1023), tx = (int)(t % tiles_x), ty = (int)(t / tiles_x);
         const int px = tx * 64 + (w & 63), lr = ty * 16 + (w >> 6);
         if (px >= W || lr >= rows) return -1;
+        if (which) {        // 1: sample rays of the occluder cache only, 2: the others only
+            const bool sample = px % RT_SHADOW_SAMPLE == 0 && lr % RT_SHADOW_SAMPLE == 0;
+            if (sample != (which == 1)) return -1;
+        }
         id = lr * W + px;
         const double* s = S + 3 * (long)id;
         const double* en = E + 3 * (long)id;
@@ -641,14 +649,14 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
 }
 
 int rt_launch_bin_rays(const double* S, const double* E, int W, int rows, int lights, long stride,
-                       int32_t* out, int* out_counts, hipStream_t st)
+                       int which, int32_t* out, int* out_counts, hipStream_t st)
 {
     if (W <= 0 || rows <= 0 || lights <= 0) return RT_OK;
     const long total = (long)((W + 63) / 64) * ((rows + 15) / 16) * 1024;
     long wgs = (total + RT_WG - 1) / RT_WG;
     if (wgs > 2048) wgs = 2048;
     hipLaunchKernelGGL(k_bin_rays, dim3((unsigned)wgs, lights), dim3(RT_WG), 0, st, S, E, W, rows, stride,
-                       out, out_counts);
+                       which, out, out_counts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("bin_rays launch failed: %s", hipGetErrorString(e));
