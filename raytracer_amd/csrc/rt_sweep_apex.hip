@@ -596,27 +596,34 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
     return RT_E_ARG;
 }
 
+// Triangle chunks an any-hit launch over `tiles` tiles may use: each at least 8 tiles long.
+static int apex_max_chunks(int tiles)
+{
+    int c = tiles / 8;
+    if (c > RT_RASTER_MAX_CHUNKS) c = RT_RASTER_MAX_CHUNKS;
+    return c < 1 ? 1 : c;
+}
+
 // Rays per lane of an any-hit launch over n rays.  The work per pair is the same for every
 // choice, but the two LDS reads per triangle and the sign-test reduction are shared by more
-// pairs with more rays per lane: 8 (at 4 waves per SIMD) is best when there are at least six
-// such workgroups per CU, 4 down to two to three workgroups per CU, and below 4 the loop is
-// bound by LDS bandwidth, which is only worth it when the machine would otherwise sit idle.
-static int apex_rays_per_lane(long n)
+// pairs with more rays per lane: below 4 the loop is bound by LDS bandwidth.  So the machine is
+// filled with triangle chunks first, and rays per lane are given up only when the chunks do
+// not suffice: 8 (at 4 waves per SIMD) wants six workgroups per CU, the others two to three.
+static int apex_rays_per_lane(long n, int max_chunks)
 {
     int r = RT_APEX_RPL;
-    if (r >= 8 && n / (RT_WG * r) < 6L * device_cus()) r = 4;
-    while (r > 1 && r <= 4 && 2 * n / (RT_WG * r) < 5L * device_cus()) r /= 2;     // 2.5 workgroups per CU
+    if (r >= 8 && (n / (RT_WG * r)) * max_chunks < 6L * device_cus()) r = 4;
+    while (r > 1 && r <= 4 && 2 * ((n + RT_WG * r - 1) / (RT_WG * r)) * max_chunks < 5L * device_cus()) r /= 2;
     return r;
 }
 
-// Triangle chunks of an any-hit launch of `wgs` workgroups in total over `tiles` tiles: enough
-// to give the machine about 8 rounds of work, each chunk at least 8 tiles long.
-static int apex_chunks(long wgs, int tiles)
+// Triangle chunks of an any-hit launch of `wgs` workgroups in total: enough to give the machine
+// about 8 rounds of work.
+static int apex_chunks(long wgs, int max_chunks)
 {
     const long slots = 5L * device_cus();
     long c = (8 * slots + wgs - 1) / wgs;
-    if (c > tiles / 8) c = tiles / 8;
-    if (c > RT_RASTER_MAX_CHUNKS) c = RT_RASTER_MAX_CHUNKS;
+    if (c > max_chunks) c = max_chunks;
     return c < 1 ? 1 : (int)c;
 }
 
@@ -631,11 +638,12 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
         return RT_E_ARG;
     }
     if (a.n_rays <= 0) return RT_OK;
-    const int r = apex_rays_per_lane(a.total_rays > 0 ? a.total_rays : (long)a.n_rays * a.lights);
+    const int max_chunks = apex_max_chunks((a.tri_end - a.tri_begin) / RT_TILE);
+    const int r = apex_rays_per_lane(a.total_rays > 0 ? a.total_rays : (long)a.n_rays * a.lights, max_chunks);
     const int per_wg = RT_WG * r;
     const unsigned wgs = (unsigned)((a.n_rays + per_wg - 1) / per_wg);
     const long all_wgs = a.total_rays > 0 ? (a.total_rays + per_wg - 1) / per_wg + a.lights : (long)wgs * a.lights;
-    const dim3 grid(wgs, a.lights, apex_chunks(all_wgs, (a.tri_end - a.tri_begin) / RT_TILE));
+    const dim3 grid(wgs, a.lights, apex_chunks(all_wgs, max_chunks));
     switch (r) {
     case 1: return launch(k_sweep_apex<1>, a, grid, st, "apex sweep");
     case 2: return launch(k_sweep_apex<2>, a, grid, st, "apex sweep");
