@@ -597,10 +597,13 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
 }
 
 // Triangle chunks an any-hit launch over `tiles` tiles may use: each at least 8 tiles long.
+// (The chunks of a ray share its count and list, so unlike the closest-hit sweep's they cost no
+// memory.)
 static int apex_max_chunks(int tiles)
 {
+    static const int cap = getenv("RT_AMD_APEX_MAX_CHUNKS") ? atoi(getenv("RT_AMD_APEX_MAX_CHUNKS")) : 32;
     int c = tiles / 8;
-    if (c > RT_RASTER_MAX_CHUNKS) c = RT_RASTER_MAX_CHUNKS;
+    if (c > cap) c = cap;
     return c < 1 ? 1 : c;
 }
 
