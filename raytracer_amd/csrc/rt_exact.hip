@@ -128,13 +128,21 @@ __device__ __forceinline__ bool confirm_list(const ExactScene& es, const double 
     return true;
 }
 
-// one atomic per wave instead of one per lane
-__device__ __forceinline__ void wave_add(int* counter, int v)
+// Statistics counters all point at one address; a workgroup adds to them once, at its end.
+__device__ __forceinline__ void block_add(int* counter, int v)
 {
+    __shared__ int s_sum;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(counter, v);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_sum, v);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum) atomicAdd(counter, s_sum);
+    __syncthreads();
 }
+
+constexpr int RESOLVE_GRID = 4096;      // grid-stride: workgroups of the resolve kernels
 
 __global__ void __launch_bounds__(RT_WG)
 k_resolve_primary(ExactScene es, int W, int H, double tan_half, RowMap rows,
@@ -143,23 +151,23 @@ k_resolve_primary(ExactScene es, int W, int H, double tan_half, RowMap rows,
                   int32_t* __restrict__ ovf, int* __restrict__ counters)
 {
     const long npix = (long)W * rows.rows;
-    const long p = (long)blockIdx.x * RT_WG + threadIdx.x;
-    int ncand = 0;
-    if (p < npix) {
+    int total = 0;
+    for (long p = (long)blockIdx.x * RT_WG + threadIdx.x; p < npix; p += (long)gridDim.x * RT_WG) {
         const int py = rows.image_row((int)(p / W)), px = (int)(p % W);
         double S[3], E[3];
         primary_ray(W, H, tan_half, px, py, S, E);
         Best b;
         bool occ;
+        int ncand;
         if (!confirm_list<false>(es, S, E, cnt, list, p, chunks, chunk_stride, b, occ, ncand)) {
             ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
-            ncand = 0;
         } else {
+            total += ncand;
             hit[p] = b.idx;
             if (b.idx != -1 && tuv) { tuv[3 * p] = b.t; tuv[3 * p + 1] = b.u; tuv[3 * p + 2] = b.v; }
         }
     }
-    wave_add(&counters[1], ncand);
+    block_add(&counters[1], total);
 }
 
 template <bool ANYHIT>
@@ -169,41 +177,40 @@ k_resolve_rays(ExactScene es, int n, const double* __restrict__ Sa, const double
                int32_t* __restrict__ hit, double* __restrict__ tuv, double* __restrict__ point,
                uint8_t* __restrict__ occ_out, int32_t* __restrict__ ovf, int* __restrict__ counters)
 {
-    const long p = (long)blockIdx.x * RT_WG + threadIdx.x;
-    const bool live = p < n && (Sa[3 * p] == Sa[3 * p]);       // NaN origin = unused ray slot
-    const unsigned long long live_mask = __ballot(live);
-    if ((threadIdx.x & 63) == 0 && live_mask) atomicAdd(&counters[4], __popcll(live_mask));
-    int ncand = 0;
-    if (p < n && !live) {
-        if (ANYHIT) occ_out[p] = 0; else hit[p] = -1;
-    }
-    Best b;
-    bool occ = false, resolved = false;
-    double S[3] = {0, 0, 0}, E[3] = {0, 0, 0};
-    if (live) {
-        S[0] = Sa[3 * p]; S[1] = Sa[3 * p + 1]; S[2] = Sa[3 * p + 2];
-        E[0] = Ea[3 * p]; E[1] = Ea[3 * p + 1]; E[2] = Ea[3 * p + 2];
-        resolved = confirm_list<ANYHIT>(es, S, E, cnt, list, p, 1, 0, b, occ, ncand);
-        if (!resolved) {
-            ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
-            ncand = 0;
+    int total = 0, live_rays = 0;
+    for (long p = (long)blockIdx.x * RT_WG + threadIdx.x; p < n; p += (long)gridDim.x * RT_WG) {
+        const double Sx = Sa[3 * p];
+        if (!(Sx == Sx)) {                      // NaN origin = unused ray slot
+            if (ANYHIT) occ_out[p] = 0; else hit[p] = -1;
+            continue;
         }
-    }
-    wave_add(&counters[1], ncand);
-    if (!resolved) return;
-    if (ANYHIT) {
-        occ_out[p] = occ ? 1 : 0;
-    } else {
-        hit[p] = b.idx;
-        if (b.idx != -1) {
-            if (tuv) { tuv[3 * p] = b.t; tuv[3 * p + 1] = b.u; tuv[3 * p + 2] = b.v; }
-            if (point) {              // triangle_intersection.cu:185-187
-                point[3 * p] = S[0] + b.t * (E[0] - S[0]);
-                point[3 * p + 1] = S[1] + b.t * (E[1] - S[1]);
-                point[3 * p + 2] = S[2] + b.t * (E[2] - S[2]);
+        ++live_rays;
+        const double S[3] = {Sx, Sa[3 * p + 1], Sa[3 * p + 2]};
+        const double E[3] = {Ea[3 * p], Ea[3 * p + 1], Ea[3 * p + 2]};
+        Best b;
+        bool occ;
+        int ncand;
+        if (!confirm_list<ANYHIT>(es, S, E, cnt, list, p, 1, 0, b, occ, ncand)) {
+            ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
+            continue;
+        }
+        total += ncand;
+        if (ANYHIT) {
+            occ_out[p] = occ ? 1 : 0;
+        } else {
+            hit[p] = b.idx;
+            if (b.idx != -1) {
+                if (tuv) { tuv[3 * p] = b.t; tuv[3 * p + 1] = b.u; tuv[3 * p + 2] = b.v; }
+                if (point) {              // triangle_intersection.cu:185-187
+                    point[3 * p] = S[0] + b.t * (E[0] - S[0]);
+                    point[3 * p + 1] = S[1] + b.t * (E[1] - S[1]);
+                    point[3 * p + 2] = S[2] + b.t * (E[2] - S[2]);
+                }
             }
         }
     }
+    block_add(&counters[1], total);
+    block_add(&counters[4], live_rays);
 }
 
 // Full fp64 sweep of triangles [begin,end) for one ray by one workgroup.  Thread k visits
@@ -473,7 +480,9 @@ int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_hal
 {
     const long npix = (long)W * rows.rows;
     if (npix <= 0) return RT_OK;
-    hipLaunchKernelGGL(k_resolve_primary, dim3((unsigned)((npix + RT_WG - 1) / RT_WG)), dim3(RT_WG),
+    long wgs = (npix + RT_WG - 1) / RT_WG;
+    if (wgs > RESOLVE_GRID) wgs = RESOLVE_GRID;
+    hipLaunchKernelGGL(k_resolve_primary, dim3((unsigned)wgs), dim3(RT_WG),
                        0, st, es, W, H, tan_half, rows, cnt, list, chunks, chunk_stride, hit, tuv, ovf, counters);
     return launched("resolve_primary");
 }
@@ -484,7 +493,7 @@ int rt_launch_resolve_rays(const ExactScene& es, int n, const double* S, const d
                            hipStream_t st)
 {
     if (n <= 0) return RT_OK;
-    dim3 grid((n + RT_WG - 1) / RT_WG);
+    dim3 grid((n + RT_WG - 1) / RT_WG < RESOLVE_GRID ? (n + RT_WG - 1) / RT_WG : RESOLVE_GRID);
     if (anyhit)
         hipLaunchKernelGGL(k_resolve_rays<true>, grid, dim3(RT_WG), 0, st, es, n, S, E, cnt, list,
                            hit, tuv, point, occ, ovf, counters);
