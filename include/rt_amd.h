@@ -175,6 +175,24 @@ int rt_render_rows_part(rt_scene* sc, const rt_frame* f, int W, int H, double ta
                         const rt_rows* rows, int32_t* hit, double* tuv, double* argb, uint8_t* rgb8);
 int rt_place_rows_part(const uint8_t* rgb8, int W, int H, const rt_rows* rows, uint8_t* screen);
 
+/* The frame loop of driver.c:28-203 as one pipelined call.  Frames first_frame,
+ * first_frame + frame_step, ... (count of them) of the orbit of rt_driver_frame_setup(frame,
+ * frames_per_turn): transform, render every row, place.  With bmp_pattern != NULL (a printf
+ * pattern with one %d, e.g. "pic/pic%04d.bmp" as driver.c:197) each picture is copied to the
+ * host on a side stream and written by background threads while the next frames render.
+ * frame_step > 1 is how ranks split a sequence without any exchange (rank r of n:
+ * first_frame + r, frame_step = n). */
+typedef struct rt_sequence_stats {
+    int    frames;                       /* frames rendered */
+    double seconds_total;                /* wall clock of the call, files closed */
+    double seconds_render;               /* of which: set-up + transform + pixel loop + placement */
+    double seconds_waiting_for_writers;  /* of which: the GPU side stalled on a full ring */
+    double seconds_writing;              /* summed over the writer threads (overlapped) */
+} rt_sequence_stats;
+int rt_render_sequence(rt_scene* sc, int first_frame, int count, int frame_step, int frames_per_turn,
+                       int W, int H, double tan_half, const char* bmp_pattern,
+                       rt_sequence_stats* stats);
+
 /* ------------------------------------------------------------------ measurement */
 typedef struct rt_profile {
     double   sweep_ms;        /* sum of HIP-event durations of closest-hit sweep launches */

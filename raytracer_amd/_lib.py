@@ -41,6 +41,11 @@ class RtRows(C.Structure):
     _fields_ = [("y0", C.c_int), ("y1", C.c_int), ("block", C.c_int), ("parts", C.c_int), ("part", C.c_int)]
 
 
+class RtSequenceStats(C.Structure):
+    _fields_ = [("frames", C.c_int), ("seconds_total", C.c_double), ("seconds_render", C.c_double),
+                ("seconds_waiting_for_writers", C.c_double), ("seconds_writing", C.c_double)]
+
+
 class RtProfile(C.Structure):
     _fields_ = [
         ("sweep_ms", C.c_double),
@@ -109,6 +114,8 @@ SIGNATURES = {
     "rt_render_rows_part": (C.c_int, [C.c_void_p, C.POINTER(RtFrame), C.c_int, C.c_int, C.c_double,
                                       C.POINTER(RtRows)] + [C.c_void_p] * 4),
     "rt_place_rows_part": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(RtRows), C.c_void_p]),
+    "rt_render_sequence": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_double, C.c_char_p, C.POINTER(RtSequenceStats)]),
     "rt_sweep_config": (C.c_int, [c_int_p] * 4),
     "rt_apex_sweep_config": (C.c_int, [c_int_p, c_int_p, C.POINTER(C.c_double), c_int_p,
                                        C.POINTER(C.c_double), c_int_p]),

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import RtFrame, RtProfile, RtRows, check
+from ._lib import RtFrame, RtProfile, RtRows, RtSequenceStats, check
 from .scenes import Mesh
 
 
@@ -256,6 +256,17 @@ class Scene:
                                                C.byref(rows_set), ptr("hit"), ptr("tuv"), ptr("argb"),
                                                ptr("rgb8")), "rt_render_rows_part")
         return o
+
+    def render_sequence(self, first_frame: int, count: int, W: int, H: int, tan_half: float,
+                        frames_per_turn: int = 60, frame_step: int = 1,
+                        bmp_pattern: str | None = None) -> RtSequenceStats:
+        """driver.c:28-203: `count` frames of the orbit, pipelined; pictures written as 32-bit
+        BMP to bmp_pattern % frame when a pattern is given."""
+        st = RtSequenceStats()
+        check(self.lib.rt_render_sequence(self.h, first_frame, count, frame_step, frames_per_turn, W, H,
+                                          float(tan_half), bmp_pattern.encode() if bmp_pattern else None,
+                                          C.byref(st)), "rt_render_sequence")
+        return st
 
     def place_rows(self, rgb8, W: int, H: int, y0: int = 0, y1: int = 0, screen=None,
                    rows_set: RtRows | None = None):
