@@ -34,6 +34,9 @@
 #ifndef RT_PREFETCH2
 #define RT_PREFETCH2 0
 #endif
+#ifndef RT_APEX_POLL
+#define RT_APEX_POLL 16     // tiles between looks at the flags other chunks may have set (power of two)
+#endif
 #ifndef RT_APEX_UNROLL
 #define RT_APEX_UNROLL 4
 #endif
@@ -179,9 +182,22 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_raster(const Swee
 // instead of a multiply and two:  U = fma(u, p_i, fma(v, p_j, p_k)).
 struct ApexRay {
     float u, v;         // the two minor components of D'; NaN once the ray has retired
-    float len;          // |apex - S|: ray parameter of the apex along the unit direction
-    float sig;          // D' = sig * (unit direction S -> apex), i.e. 1 / (unit direction)_k
 };
+
+// What only the rare path needs of a ray is not kept in registers (it would cost the hot loop a
+// wave of occupancy) but read again: its number, and from its end points
+//   len = |apex - S|, the ray parameter of the apex along the unit direction, and
+//   sig = 1 / (unit direction)_k, so that D' = sig * unit direction.
+template <int AX>
+__device__ __forceinline__ void ray_tail(const SweepArgs& A, int sl, float& len, float& sig)
+{
+    const double* s = A.S + 3 * (long)sl;
+    const double* e = A.E + 3 * (long)sl;
+    const double dx = e[0] - s[0], dy = e[1] - s[1], dz = e[2] - s[2];
+    const double l = __builtin_sqrt(dx * dx + dy * dy + dz * dz);
+    len = (float)l;
+    sig = (float)(l / (AX == 0 ? dx : (AX == 1 ? dy : dz)));
+}
 
 template <int AX>
 __device__ __forceinline__ float dot_ax(float u, float v, const float4& p)
@@ -191,17 +207,17 @@ __device__ __forceinline__ float dot_ax(float u, float v, const float4& p)
     return __builtin_fmaf(u, p.x, __builtin_fmaf(v, p.y, p.z));                  // D' = (u, v, 1)
 }
 
-// candidate() for an any-hit sweep whose triangle range is shared by several workgroups per
-// ray: the candidate count and the occluded flag of a ray live in global memory only and are
-// updated atomically.  The order of a ray's list entries is then arbitrary, which an any-hit
-// query does not care about (triangle_intersection.cu:169 asks for any dist > 0).
-__device__ __forceinline__ void candidate_shared(Book& r, int32_t* __restrict__ cnt_slot,
+// The counterpart of candidate() for an any-hit sweep whose triangle range is shared by several
+// workgroups per ray: the candidate count and the occluded flag of a ray live in global memory
+// only and are updated atomically.  The order of a ray's list entries is then arbitrary, which
+// an any-hit query does not care about (triangle_intersection.cu:169 asks for any dist > 0).
+// Returns true when the pair is a certain hit (the ray retires).
+__device__ __forceinline__ bool candidate_shared(int32_t* __restrict__ cnt_slot,
                                                  int32_t* __restrict__ list_slot,
                                                  int32_t* __restrict__ occ_slot, int tri, float a,
                                                  float b, float w, float d, float T, float t0,
                                                  float margin, float en, float eT)
 {
-    if (r.best_hi == -INF) return;
     const float ad = __builtin_fabsf(d);
     const float den = ad - en;
     bool certain = false;
@@ -210,54 +226,65 @@ __device__ __forceinline__ void candidate_shared(Book& r, int32_t* __restrict__ 
         const float t = t0 + q;
         const float terr = (eT + __builtin_fabsf(q) * en) / den * 1.000001f +
                            U22 * (__builtin_fabsf(t0) + __builtin_fabsf(q));
-        if (!(t >= -terr)) return;
+        if (!(t >= -terr)) return false;
         certain = (__builtin_fminf(__builtin_fminf(a, b), w) >= margin * ad) && (t > terr);
     }
     if (certain) {
         atomicOr(cnt_slot, RT_CNT_OCCLUDED);    // the list no longer matters
         if (occ_slot) *occ_slot = tri;          // for the occluder cache (any certain occluder will do)
-        r.best_hi = -INF;
-        return;
+        return true;
     }
     const int at = atomicAdd(cnt_slot, 1) & RT_CNT_MASK;
     if (at < RT_LIST_K) list_slot[at] = tri;
+    return false;
 }
 
+// The rest of the inside test for one ray (u, v = minor components of D') that passed the slab
+// test of triangle `tri`; Hh, N = the triangle's planes 2 and 3.  Returns true when the ray
+// retires.  What only this path needs of a ray -- its number, len and sig -- is read again from
+// memory rather than kept in registers.
 template <int AX>
-__device__ __forceinline__ void finish_apex(Book& bk, const ApexRay& r, int32_t* __restrict__ cnt_slot,
-                                            int32_t* __restrict__ list_slot, int32_t* __restrict__ occ_slot,
-                                            int tri, const Tri2& q, const float4* __restrict__ p)
+__device__ __forceinline__ bool finish_apex(const SweepArgs& A, float u, float v, long jr, int tri,
+                                            const Tri2& q, const float4& Hh, const float4& N)
 {
-    const float4 Hh = p[2 * RT_TILE], N = p[3 * RT_TILE];
     const float margin = q.Q.w;
-    if (margin == INF) {
-        if (bk.best_hi != -INF) {
-            const int at = atomicAdd(cnt_slot, 1) & RT_CNT_MASK;
-            if (at < RT_LIST_K) list_slot[at] = tri;
-        }
-        return;
-    }
-    const float U = dot_ax<AX>(r.u, r.v, q.P);
-    const float V = dot_ax<AX>(r.u, r.v, Hh);
-    const float d = dot_ax<AX>(r.u, r.v, N);
-    const float a = U * d, b = V * d;
-    const float w = __builtin_fmaf(d, d, -a) - b;
-    const float m3 = __builtin_fminf(__builtin_fminf(a, b), w);
-    if (__builtin_fmaf(margin, __builtin_fabsf(d), m3) > 0.0f) {
+    if (margin != INF) {            // INF: nearly degenerate triangle, no fp32 verdict
+        const float U = dot_ax<AX>(u, v, q.P);
+        const float V = dot_ax<AX>(u, v, Hh);
+        const float d = dot_ax<AX>(u, v, N);
+        const float a = U * d, b = V * d;
+        const float w = __builtin_fmaf(d, d, -a) - b;
+        const float m3 = __builtin_fminf(__builtin_fminf(a, b), w);
+        if (!(__builtin_fmaf(margin, __builtin_fabsf(d), m3) > 0.0f)) return false;
+        const int sl = A.active[jr];
+        float len, sig;
+        ray_tail<AX>(A, sl, len, sig);
         // The triangle's plane meets the line apex + tau * D' at tau = k / (D'.nn).  Along the
         // unit direction, from S: t = len + sig * tau (the reference's t times len; only its
         // sign matters for an any-hit query, triangle_intersection.cu:169).
-        const float T = r.sig * Hh.w;
-        candidate_shared(bk, cnt_slot, list_slot, occ_slot, tri, a, b, w, d, T, r.len, margin, N.w,
-                         U22 * __builtin_fabsf(T));
+        const float T = sig * Hh.w;
+        return candidate_shared(A.cnt + sl, A.list + (long)sl * RT_LIST_K,
+                                A.occ_id ? A.occ_id + sl : nullptr, tri, a, b, w, d, T, len, margin,
+                                N.w, U22 * __builtin_fabsf(T));
     }
+    const int sl = A.active[jr];
+    const int at = atomicAdd(A.cnt + sl, 1) & RT_CNT_MASK;
+    if (at < RT_LIST_K) A.list[(long)sl * RT_LIST_K + at] = tri;
+    return false;
 }
 
-// The tile loop of one workgroup for rays of dominant axis AX.
+// The tile loop of one workgroup for rays of dominant axis AX.  A ray is retired when its u is
+// NaN: its slab value is NaN too and never passes.
+//
+// Shadow rays that survive a few ranges are scattered over the image, so for almost every
+// triangle SOME ray of a wave lies in its slab; what is rare is that one lane has more than one
+// such ray.  The slab passes are therefore handled lane-wise: every lane picks its first passing
+// ray (a chain of selects), the wave finishes those together, and the loop repeats only while
+// some lane has another one.
 template <int AX, int R>
 __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT_APEX_PLANES][RT_TILE],
-                                           ApexRay (&ray)[R], Book (&bk)[R], const int (&slot)[R],
-                                           int wave, int lane, unsigned long long& tiles_done)
+                                           ApexRay (&ray)[R], long j0, int wave, int lane,
+                                           unsigned long long& tiles_done)
 {
     const float qnan = __builtin_nanf("");
     // this workgroup's share of the triangle range: chunk blockIdx.z of gridDim.z
@@ -291,33 +318,40 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
 #pragma unroll
             for (int r = 1; r < R; ++r) mx = __builtin_fmaxf(mx, s[r]);
             if (__builtin_expect(mx >= 0.0f, 0)) {
+                const float4 Hh = base[j + 2 * RT_TILE], N = base[j + 3 * RT_TILE];
+                unsigned pass = 0;
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (s[r] >= 0.0f) {
-                        // the ray's addresses are formed here, in the rare path: hoisted out of the
-                        // loop they would cost four more registers per ray
-                        int sl = slot[r];
-                        asm volatile("" : "+v"(sl));
-                        finish_apex<AX>(bk[r], ray[r], A.cnt + sl, A.list + (long)sl * RT_LIST_K,
-                                        A.occ_id ? A.occ_id + sl : nullptr, tri0 + j, cur, base + j);
-                        if (bk[r].best_hi == -INF) ray[r].u = qnan;
+                for (int r = 0; r < R; ++r) pass |= (s[r] >= 0.0f ? 1u : 0u) << r;
+                while (pass) {
+                    const int rs = __builtin_ctz(pass);
+                    pass &= pass - 1;
+                    float u = ray[0].u, v = ray[0].v;
+#pragma unroll
+                    for (int r = 1; r < R; ++r) {
+                        u = rs == r ? ray[r].u : u;
+                        v = rs == r ? ray[r].v : v;
                     }
+                    if (finish_apex<AX>(A, u, v, j0 + (long)rs * RT_WG, tri0 + j, cur, Hh, N)) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) ray[r].u = rs == r ? qnan : ray[r].u;
+                    }
+                }
             }
         }
         ++tiles_done;
         __builtin_amdgcn_s_waitcnt(0);
         // retire the workgroup once every ray in it is certainly occluded or unused; with
         // several chunks per ray the flag another chunk's workgroup may have set is polled
+        // every few tiles (two dependent loads per ray: not free)
         bool done = true;
+        const bool poll = gridDim.z > 1 && ((t - t_begin) & (RT_APEX_POLL - 1)) == RT_APEX_POLL - 1;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if (gridDim.z > 1 && bk[r].best_hi != -INF &&
-                (__hip_atomic_load(&A.cnt[slot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
-                 RT_CNT_OCCLUDED)) {
-                bk[r].best_hi = -INF;
+            if (poll && ray[r].u == ray[r].u &&
+                (__hip_atomic_load(&A.cnt[A.active[j0 + r * RT_WG]], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT) & RT_CNT_OCCLUDED))
                 ray[r].u = qnan;
-            }
-            done = done && (bk[r].best_hi == -INF);
+            done = done && !(ray[r].u == ray[r].u);
         }
         if (__syncthreads_and(done)) break;
     }
@@ -327,8 +361,6 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
 // the n = live_counts[s] ray numbers active[s * light_ray_stride ...]; the rays, counts and
 // lists of light l start l * light_ray_stride rays into their arrays, its planes
 // l * light_plane_stride float4 into theirs.
-// (8 rays per lane fit 4 waves per SIMD only with the rare path's temporaries spilled; measured
-// 4 % faster on the whole frame than 4 rays per lane without spills)
 template <int R>
 __global__ void __launch_bounds__(RT_WG, R >= 8 ? 4 : RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
 {
@@ -351,45 +383,41 @@ __global__ void __launch_bounds__(RT_WG, R >= 8 ? 4 : RT_MIN_WAVES) k_sweep_apex
     if ((long)blockIdx.x * (RT_WG * R) >= A.n_rays) return;     // the grid is sized for the largest set
 
     ApexRay ray[R];
-    Book bk[R];
-    int slot[R];
     const float qnan = __builtin_nanf("");
+    const long j0 = (long)blockIdx.x * (RT_WG * R) + tid;      // ray r of this lane: active[j0 + r * RT_WG]
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const long j = (long)blockIdx.x * (RT_WG * R) + r * RT_WG + tid;
+        const long j = j0 + r * RT_WG;
         bool valid = j < A.n_rays;
-        slot[r] = valid ? A.active[j] : 0;
-        double D[3] = {0, 0, 0}, len = 0, sig = 0;
+        double D[3] = {0, 0, 0};
         if (valid) {
-            const double* s = A.S + 3 * (long)slot[r];
-            const double* e = A.E + 3 * (long)slot[r];
+            const int sl = A.active[j];
+            const double* s = A.S + 3 * (long)sl;
+            const double* e = A.E + 3 * (long)sl;
             D[0] = e[0] - s[0]; D[1] = e[1] - s[1]; D[2] = e[2] - s[2];
-            len = __builtin_sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
-            const double dk = axis == 0 ? D[0] : (axis == 1 ? D[1] : D[2]);
-            sig = len / dk;                         // 1 / (unit direction)_k
+            const double len = __builtin_sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
+            const double sig = len / (axis == 0 ? D[0] : (axis == 1 ? D[1] : D[2]));
             // listed rays have a finite, non-zero direction (k_bin_rays); be safe regardless
             if (!(len > 0) || !(sig == sig) || sig > 1e300 || sig < -1e300) valid = false;
             // the ray's count and flags live in cnt[] (zeroed by the host before the first range)
-            if (A.cnt[slot[r]] & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) valid = false;
+            if (A.cnt[sl] & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) valid = false;
         }
         const double du = (axis == 0 ? D[1] : D[0]), dv = (axis == 2 ? D[1] : D[2]);
         const double dk = axis == 0 ? D[0] : (axis == 1 ? D[1] : D[2]);
-        bk[r].best = INF;
-        bk[r].best_hi = valid ? INF : -INF;
-        bk[r].cnt = 0;
-        // a retired ray carries a NaN direction: s is NaN and never enters the rare path
+        // a retired ray carries a NaN direction: s is NaN and never passes the slab test
         ray[r].u = valid ? (float)(du / dk) : qnan;
         ray[r].v = valid ? (float)(dv / dk) : qnan;
-        ray[r].len = (float)len;
-        ray[r].sig = (float)sig;
+        // one ray at a time: interleaving the fp64 set-up of all rays would make this prologue,
+        // not the hot loop, decide the kernel's register count and with it the occupancy
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     unsigned long long tiles_done = 0;
     switch (axis) {         // uniform over the workgroup
-    case 0: apex_tiles<0, R>(A, tile, ray, bk, slot, wave, lane, tiles_done); break;
-    case 1: apex_tiles<1, R>(A, tile, ray, bk, slot, wave, lane, tiles_done); break;
-    default: apex_tiles<2, R>(A, tile, ray, bk, slot, wave, lane, tiles_done); break;
+    case 0: apex_tiles<0, R>(A, tile, ray, j0, wave, lane, tiles_done); break;
+    case 1: apex_tiles<1, R>(A, tile, ray, j0, wave, lane, tiles_done); break;
+    default: apex_tiles<2, R>(A, tile, ray, j0, wave, lane, tiles_done); break;
     }
 
     if (A.tests && tid == 0)
