@@ -34,6 +34,9 @@
 #ifndef RT_PREFETCH2
 #define RT_PREFETCH2 0
 #endif
+#ifndef RT_APEX8_WAVES
+#define RT_APEX8_WAVES 5    // waves per SIMD the 8-rays-per-lane any-hit kernel must fit
+#endif
 #ifndef RT_APEX_POLL
 #define RT_APEX_POLL 16     // tiles between looks at the flags other chunks may have set (power of two)
 #endif
@@ -362,7 +365,7 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
 // lists of light l start l * light_ray_stride rays into their arrays, its planes
 // l * light_plane_stride float4 into theirs.
 template <int R>
-__global__ void __launch_bounds__(RT_WG, R >= 8 ? 4 : RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
+__global__ void __launch_bounds__(RT_WG, R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
 {
     __shared__ float4 tile[2][RT_APEX_PLANES][RT_TILE];
 
