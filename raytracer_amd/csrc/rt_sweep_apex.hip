@@ -18,8 +18,12 @@
 // v and u+v edges, the ray parameter) and appends survivors to the ray's candidate list; the
 // fp64 pass of rt_exact.hip then decides with the reference's exact arithmetic.
 //
-//   k_sweep_apex    any-hit, unit-length directions: two 3-term dot products + the product
-//                   test = 8 VALU instructions per pair.
+//   k_sweep_apex    any-hit, for the shadow rays of up to four lights.  Directions are scaled to
+//                   a unit dominant component (rays binned by that axis, k_bin_rays), so a dot
+//                   product is two FMAs: 5 FMA + the sign test = 5.6 VALU instructions per pair.
+//                   Triangle ranges with survivor compaction in between, triangle chunks that
+//                   share a ray's state through atomics, an occluder cache in front (host side:
+//                   trace_shadow_rays in rt_api.hip).
 //   k_sweep_raster  closest hit for the pixel grid.  D = (X, Y, ez) with integer X, Y and a
 //                   constant ez that k_pack_apex folds into the z components, and each lane
 //                   owns RT_RASTER_RPL pixels of one row, so the row part Y*p.y + ez*p.z is
@@ -31,9 +35,6 @@
 // at wave-uniform addresses (broadcast, no bank conflicts).
 #include "rt_sweep_common.h"
 
-#ifndef RT_PREFETCH2
-#define RT_PREFETCH2 0
-#endif
 #ifndef RT_APEX8_WAVES
 #define RT_APEX8_WAVES 5    // waves per SIMD the 8-rays-per-lane any-hit kernel must fit
 #endif
@@ -129,20 +130,11 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_raster(const Swee
         const int tri0 = t * RT_TILE;
         // LDS reads are issued one triangle ahead by hand (the rare path splits the body into
         // basic blocks, which keeps the compiler from hoisting them)
-#if RT_PREFETCH2
-        Tri2 next = load_tri2(base), next2 = load_tri2(base + 1);
-#else
         Tri2 next = load_tri2(base);
-#endif
 #pragma unroll kRasterUnroll
         for (int j = 0; j < RT_TILE; ++j) {
             const Tri2 cur = next;
-#if RT_PREFETCH2
-            next = next2;
-            next2 = load_tri2(base + ((j + 2) & (RT_TILE - 1)));    // the last two iterations re-read entries 0, 1 (unused)
-#else
             next = load_tri2(base + ((j + 1) & (RT_TILE - 1)));     // last iteration re-reads entry 0 (unused)
-#endif
             const float yu = __builtin_fmaf(Y, cur.P.y, cur.P.z);
             const float yw = __builtin_fmaf(Y, cur.Q.y, cur.Q.z);
             float s[R];
