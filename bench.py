@@ -261,6 +261,10 @@ def main() -> None:
             "hit_fraction_rank0": hit_frac,
             "fp64_confirmations_per_frame": tsum[8].item() / steps,
             "overflow_rays_per_frame": tsum[9].item() / steps,
+            # rank 0's any-hit sweeps (shadow rays): HIP-event time of all their launches per frame
+            "shadow_sweeps_rank0": {"ms_per_frame": prof.shadow_ms / steps,
+                                    "tests_per_frame": prof.shadow_tests / steps,
+                                    "launches_per_frame": prof.shadow_launches / steps},
             # Roofline of the dominant kernel.  `achieved` prices a ray-triangle pair at the fp32
             # flops the hot loop executes for it (rocprof SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 agree
             # within 2 %, see profiles/), because the kernel uses the shared origin of the primary

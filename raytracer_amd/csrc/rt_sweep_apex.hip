@@ -326,7 +326,7 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
                         u = rs == r ? ray[r].u : u;
                         v = rs == r ? ray[r].v : v;
                     }
-                    if (finish_apex<AX>(A, u, v, j0 + (long)rs * RT_WG, tri0 + j, cur, Hh, N)) {
+                    if (finish_apex<AX>(A, u, v, j0 + (long)rs * 64, tri0 + j, cur, Hh, N)) {
 #pragma unroll
                         for (int r = 0; r < R; ++r) ray[r].u = rs == r ? qnan : ray[r].u;
                     }
@@ -343,7 +343,7 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (poll && ray[r].u == ray[r].u &&
-                (__hip_atomic_load(&A.cnt[A.active[j0 + r * RT_WG]], __ATOMIC_RELAXED,
+                (__hip_atomic_load(&A.cnt[A.active[j0 + r * 64]], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT) & RT_CNT_OCCLUDED))
                 ray[r].u = qnan;
             done = done && !(ray[r].u == ray[r].u);
@@ -379,11 +379,14 @@ __global__ void __launch_bounds__(RT_WG, R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES)
 
     ApexRay ray[R];
     const float qnan = __builtin_nanf("");
-    const long j0 = (long)blockIdx.x * (RT_WG * R) + tid;      // ray r of this lane: active[j0 + r * RT_WG]
+    // a wave owns 64 R consecutive rays of the list (neighbours on the screen: the fewer
+    // triangles have any of them in their slab, the fewer rare-path entries the wave pays for);
+    // ray r of this lane: active[j0 + r * 64]
+    const long j0 = (long)blockIdx.x * (RT_WG * R) + wave * (64 * R) + lane;
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const long j = j0 + r * RT_WG;
+        const long j = j0 + r * 64;
         bool valid = j < A.n_rays;
         double D[3] = {0, 0, 0};
         if (valid) {

@@ -109,6 +109,9 @@ k_pack(const double* __restrict__ x, const double* __restrict__ y, const double*
 // determinant in the reference for every ray and can never be hit: it is stored as a null
 // entry (c = -1).  A nearly degenerate one gets m = +inf, which sends every pair inside its
 // slab to the exact pass.
+#ifndef RT_PACK_ROTATE
+#define RT_PACK_ROTATE 1
+#endif
 __global__ void __launch_bounds__(RT_WG)
 k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
             const int* __restrict__ iA, const int* __restrict__ iB, const int* __restrict__ iC,
@@ -128,6 +131,37 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
         a0x = x[a] - px; a0y = y[a] - py; a0z = z[a] - pz;
         a1x = x[b] - px; a1y = y[b] - py; a1z = z[b] - pz;
         a2x = x[c] - px; a2y = y[c] - py; a2z = z[c] - pz;
+#if RT_PACK_ROTATE
+        // The sweep's first test is the u slab: the strip between the line through a0 and a2 and
+        // its parallel through a1.  Which vertex is called a0 does not matter to the filter
+        // (the inside test and its bounds are symmetric under a rotation of the labels, and the
+        // exact pass works from the reference's own order), so the labels are rotated to make
+        // that strip the narrowest of the three: the edge a0-a2 becomes the one that looks
+        // longest from P, and fewer rays lie in the slab.
+        const double r0s = a0x * a0x + a0y * a0y + a0z * a0z;
+        const double r1s = a1x * a1x + a1y * a1y + a1z * a1z;
+        const double r2s = a2x * a2x + a2y * a2y + a2z * a2z;
+        auto sin2 = [](double ux, double uy, double uz, double vx, double vy, double vz, double us, double vs) {
+            const double cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
+            return (cx * cx + cy * cy + cz * cz) / (us * vs);
+        };
+        if (r0s > 0.0 && r1s > 0.0 && r2s > 0.0) {
+            const double s02 = sin2(a0x, a0y, a0z, a2x, a2y, a2z, r0s, r2s);
+            const double s01 = sin2(a0x, a0y, a0z, a1x, a1y, a1z, r0s, r1s);
+            const double s12 = sin2(a1x, a1y, a1z, a2x, a2y, a2z, r1s, r2s);
+            if (s01 > s02 && s01 >= s12) {          // (a0, a1, a2) <- (a1, a2, a0)
+                const double tx = a0x, ty = a0y, tz = a0z;
+                a0x = a1x; a0y = a1y; a0z = a1z;
+                a1x = a2x; a1y = a2y; a1z = a2z;
+                a2x = tx; a2y = ty; a2z = tz;
+            } else if (s12 > s02 && s12 > s01) {    // (a0, a1, a2) <- (a2, a0, a1)
+                const double tx = a2x, ty = a2y, tz = a2z;
+                a2x = a1x; a2y = a1y; a2z = a1z;
+                a1x = a0x; a1y = a0y; a1z = a0z;
+                a0x = tx; a0y = ty; a0z = tz;
+            }
+        }
+#endif
     }
     const double e1x = a1x - a0x, e1y = a1y - a0y, e1z = a1z - a0z;
     const double e2x = a2x - a0x, e2y = a2y - a0y, e2z = a2z - a0z;

@@ -6,6 +6,6 @@ for n in default "$@"; do
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('frame ms', round(d['ms_per_step'],1), 'primary ms', round(d['roofline']['avg_launch_ms'],1), 'tests/s', '%.3e'%d['tests_per_s'])
+        d=json.loads(l); print('frame ms', round(d['ms_per_step'],1), 'primary ms', round(d['roofline']['avg_launch_ms'],1), 'tests/s', '%.3e'%d['tests_per_s'], 'shadow ms', round(d['shadow_sweeps_rank0']['ms_per_frame'],1), 'shadow tests', '%.3e'%d['shadow_sweeps_rank0']['tests_per_frame'])
 " || exit 1
 done
