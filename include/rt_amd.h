@@ -156,8 +156,10 @@ int rt_place_rows(const uint8_t* rgb8, int W, int H, int y0, int y1, uint8_t* sc
 /* Row band of rank r out of n: contiguous, remainder to the last ranks one row each. */
 int rt_band(int H, int nranks, int rank, int* y0, int* y1);
 
-/* A row set that interleaves parts: of the rows [y0,y1), cut into blocks of `block` rows, part
- * `part` of `parts` holds blocks part, part + parts, part + 2*parts, ...  Its rows are numbered
+/* A row set that interleaves parts: the rows [y0,y1) are cut into blocks of `block` rows and the
+ * blocks are dealt to the parts in rounds of `parts`, forwards in even rounds (block
+ * round*parts + part) and backwards in odd ones (block round*parts + parts-1-part), so that a
+ * cost that grows steadily down the image is shared evenly.  The rows of a part are numbered
  * locally 0 .. rt_rows_count()-1 in ascending image order, and the outputs of the *_part calls
  * are indexed [local_row * W + x_pix].  parts = 1 is the contiguous band.  Interleaving is how
  * the pixel loop of driver.c:126-193 is split over GPUs when the cost per row is uneven (the

@@ -163,7 +163,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts,
                       &sc->scratch_max, &sc->mat_dev, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
-                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid};
+                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : sc->tex_data) b.release();
     delete sc;
@@ -523,7 +523,9 @@ static int rows_of_part(const rt_rows* r)
     const int total = r->y1 - r->y0;
     const int nblocks = (total + r->block - 1) / r->block;
     int rows = 0;
-    for (int b = r->part; b < nblocks; b += r->parts) {
+    for (int round = 0; round * r->parts < nblocks; ++round) {
+        const int b = round * r->parts + ((round & 1) ? r->parts - 1 - r->part : r->part);
+        if (b >= nblocks) continue;         // only in the last round
         const int left = total - b * r->block;
         rows += left < r->block ? left : r->block;
     }
@@ -665,6 +667,14 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
     if ((double)np * (double)total < 1.5e10) first = np;
     int begin = 0, len = first, cur = 0;
     bool indexed = binned;
+    // a long sweep of binned rays (they all end at their light): order every set by direction
+    // as seen from the light first (rt_sort.hip)
+    static const bool sort_rays = !(getenv("RT_AMD_SORT_RAYS") && atoi(getenv("RT_AMD_SORT_RAYS")) == 0);
+    if (binned && sort_rays && first < np && total > 0) {
+        RT_TRY(rt_launch_sort_rays(sc, a.S, a.E, act[0], act[1], counts, live_dev[0], sets, stride, st));
+        RT_HIP(hipMemcpyAsync(live_dev[1], live_dev[0], sizeof(int) * RT_APEX_SETS, hipMemcpyDeviceToDevice, st));
+        cur = 1;
+    }
     while (begin < np && live > 0) {
         int end = begin + len;
         if (end > np || np - end < len / 2) end = np;

@@ -115,7 +115,7 @@ struct rt_scene {
 
     // per-call workspaces (grow-only)
     DevBuf ws_cnt, ws_list, ws_ovf, ws_counters;
-    DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_act2, ws_live, ws_occid;
+    DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_act2, ws_live, ws_occid, ws_sort;
 };
 
 struct DevMaterial {
@@ -161,15 +161,18 @@ int rt_launch_pack(rt_scene* sc, hipStream_t st);
 int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, int set,
                         hipStream_t st);      // into plane set `set` of sc->planes_apex
 
-// The pixel rows one call works on.  Local row lr (0 .. rows-1) is image row
-//     y0 + ((lr / block) * parts + part) * block + lr % block,
-// i.e. every parts-th block of `block` rows starting with block `part`; parts = 1 is the
-// contiguous band [y0, y0 + rows).  Outputs are indexed by local row.
+// The pixel rows one call works on: one block of `block` rows out of every `parts` (rt_rows in
+// the public header); parts = 1 is the contiguous band [y0, y0 + rows).  Outputs are indexed by
+// local row lr (0 .. rows-1).
 struct RowMap {
     int y0, rows, block, parts, part;
+    // blocks are dealt to the parts in rounds, forwards in even rounds and backwards in odd
+    // ones, so that a cost that grows steadily down the image is shared evenly
     __host__ __device__ int image_row(int lr) const
     {
-        return y0 + ((lr / block) * parts + part) * block + lr % block;
+        const int round = lr / block;
+        const int slot = (round & 1) ? parts - 1 - part : part;
+        return y0 + (round * parts + slot) * block + lr % block;
     }
 };
 inline RowMap rt_band_rows(int y0, int y1) { return RowMap{y0, y1 - y0, y1 - y0 > 0 ? y1 - y0 : 1, 1, 0}; }
@@ -216,7 +219,7 @@ int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st);
 int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st);   // primary rays, closest hit
 // launch shape of the pixel-grid sweep for a band of W x rows pixels and `tiles` triangle tiles:
 // pixels per lane (<= RT_RASTER_RPL) and the number of triangle chunks (<= RT_RASTER_MAX_CHUNKS)
-constexpr int RT_RASTER_MAX_CHUNKS = 8;
+constexpr int RT_RASTER_MAX_CHUNKS = 24;
 void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks);
 int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st);     // any-hit over binned ray lists
 // shadow rays [light][pixel] -> ray-number lists per (light, dominant axis), stride entries apart
@@ -228,6 +231,9 @@ constexpr int RT_SHADOW_SAMPLE = 4;
 // survivors of `sets` ray sets (stride entries apart in in/out; cnt of set s starts
 // (s / cnt_div) * stride rays in): set s takes its n from in_counts[s] when `in` is given, else
 // all n rays; writes out_counts[s]
+int rt_launch_sort_rays(rt_scene* sc, const double* S, const double* E, const int32_t* ids_in,
+                        int32_t* ids_out, const int* counts, const int* counts_dev, int sets,
+                        long stride, hipStream_t st);
 int rt_launch_compact(const int32_t* cnt, const int32_t* in, const int* in_counts, int n, int sets,
                       long stride, int cnt_div, int32_t* out, int* out_counts, hipStream_t st);
 

@@ -1,0 +1,97 @@
+// rt_sort.hip -- orders the shadow rays of a set by direction as seen from their light.
+//
+// The any-hit sweep (rt_sweep_apex.hip) pays for a triangle's rare path whenever ANY of a
+// wave's 64 R rays lies in the triangle's u slab.  Rays of neighbouring pixels are neighbours
+// on a smooth surface, but where neighbouring pixels see different depths (a triangle soup,
+// silhouettes) their shadow rays fan out along the light's epipolar lines.  Ordering the rays
+// of a set by a Morton code of the two minor components of D' = D / D_k makes every wave's
+// rays a narrow bundle through the light, which fewer slabs cross, and whose rays tend to
+// share occluders and retire together.  An any-hit query does not depend on the order in
+// which rays are swept, so the results are unchanged.
+#include "rt_internal.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace {
+
+struct KeyArgs {
+    int key_off[RT_APEX_SETS];      // where the keys of set s start in the packed key array
+};
+
+__device__ __forceinline__ unsigned spread_bits(unsigned x)     // bit i of 12 -> bit 2 i
+{
+    x &= 0xFFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+// blockIdx.y = set = light * 3 + dominant axis; ids of set s at ids[s * stride ...], n = counts[s]
+__global__ void __launch_bounds__(RT_WG)
+k_ray_keys(const double* __restrict__ S, const double* __restrict__ E, const int32_t* __restrict__ ids,
+           const int* __restrict__ counts, long stride, KeyArgs ka, unsigned* __restrict__ keys)
+{
+    const int set = blockIdx.y, light = set / 3, axis = set - 3 * light;
+    const int n = counts[set];
+    S += 3 * light * stride;
+    E += 3 * light * stride;
+    ids += set * stride;
+    keys += ka.key_off[set];
+    for (int i = blockIdx.x * RT_WG + threadIdx.x; i < n; i += gridDim.x * RT_WG) {
+        const long id = ids[i];
+        const double dx = E[3 * id] - S[3 * id], dy = E[3 * id + 1] - S[3 * id + 1],
+                     dz = E[3 * id + 2] - S[3 * id + 2];
+        const double dk = axis == 0 ? dx : (axis == 1 ? dy : dz);
+        const double du = axis == 0 ? dy : dx, dv = axis == 2 ? dy : dz;
+        // minor components in [-1, 1] -> 12 bits each; opposite directions are different bundles
+        const float u = (float)(du / dk), v = (float)(dv / dk);
+        const unsigned qu = (unsigned)fminf(fmaxf((u + 1.0f) * 2047.5f, 0.0f), 4095.0f);
+        const unsigned qv = (unsigned)fminf(fmaxf((v + 1.0f) * 2047.5f, 0.0f), 4095.0f);
+        keys[i] = spread_bits(qu) | (spread_bits(qv) << 1) | (dk < 0.0 ? 1u << 24 : 0u);
+    }
+}
+
+}  // namespace
+
+// Sorts the ray numbers of every set (ids_in[s * stride ...], counts[s] of them; counts_dev the
+// same numbers on the device) by direction into ids_out.  Sets smaller than min_rays are copied.
+int rt_launch_sort_rays(rt_scene* sc, const double* S, const double* E, const int32_t* ids_in,
+                        int32_t* ids_out, const int* counts, const int* counts_dev, int sets,
+                        long stride, hipStream_t st)
+{
+    KeyArgs ka{};
+    long total = 0;
+    unsigned largest = 0;
+    for (int s = 0; s < sets; ++s) {
+        ka.key_off[s] = (int)total;
+        total += counts[s];
+        if ((unsigned)counts[s] > largest) largest = (unsigned)counts[s];
+    }
+    if (total == 0) return RT_OK;
+    size_t temp_bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, temp_bytes, (unsigned*)nullptr, (unsigned*)nullptr,
+                                  (int32_t*)nullptr, (int32_t*)nullptr, largest, 0u, 25u, st) != hipSuccess) {
+        rt_set_error("ray sort: size query failed");
+        return RT_E_HIP;
+    }
+    const size_t key_bytes = ((size_t)total * sizeof(unsigned) + 255) & ~(size_t)255;
+    if (int rc = sc->ws_sort.reserve(2 * key_bytes + temp_bytes)) return rc;
+    unsigned* keys_in = sc->ws_sort.as<unsigned>();
+    unsigned* keys_out = reinterpret_cast<unsigned*>(sc->ws_sort.as<char>() + key_bytes);
+    void* temp = sc->ws_sort.as<char>() + 2 * key_bytes;
+    unsigned wgs = (largest + RT_WG - 1) / RT_WG;
+    if (wgs > 2048) wgs = 2048;
+    hipLaunchKernelGGL(k_ray_keys, dim3(wgs, sets), dim3(RT_WG), 0, st, S, E, ids_in, counts_dev, stride, ka,
+                       keys_in);
+    RT_HIP(hipGetLastError());
+    for (int s = 0; s < sets; ++s) {
+        if (counts[s] == 0) continue;
+        size_t bytes = temp_bytes;
+        RT_HIP(rocprim::radix_sort_pairs(temp, bytes, keys_in + ka.key_off[s], keys_out + ka.key_off[s],
+                                         ids_in + s * stride, ids_out + s * stride, (unsigned)counts[s],
+                                         0u, 25u, st));
+    }
+    return RT_OK;
+}

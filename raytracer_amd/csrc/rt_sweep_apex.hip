@@ -574,13 +574,14 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     const long tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
     int max_chunks = tiles / 8;
     if (max_chunks < 1) max_chunks = 1;
-    if (max_chunks > RT_RASTER_MAX_CHUNKS) max_chunks = RT_RASTER_MAX_CHUNKS;
+    static const int cap = getenv("RT_AMD_RASTER_MAX_CHUNKS") ? atoi(getenv("RT_AMD_RASTER_MAX_CHUNKS")) : RT_RASTER_MAX_CHUNKS;
+    if (max_chunks > cap) max_chunks = cap;
     int r = RT_RASTER_RPL;
     while (r > 1 && 16 * r > W + 8 * r) r /= 2;         // no lane set mostly off the image
     for (;;) {
         const long wgs = (long)((W + 16 * r - 1) / (16 * r)) * tiles_y;
         if (wgs * max_chunks >= slots || r == 1) {
-            long c = (32 * slots + wgs - 1) / wgs;      // about 32 rounds are fine-grained enough
+            long c = (24 * slots + wgs - 1) / wgs;      // about 24 rounds are fine-grained enough
             if (c > max_chunks) c = max_chunks;
             if (c < 1) c = 1;
             *pixels_per_lane = r;
@@ -627,7 +628,7 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
 // memory.)
 static int apex_max_chunks(int tiles)
 {
-    static const int cap = getenv("RT_AMD_APEX_MAX_CHUNKS") ? atoi(getenv("RT_AMD_APEX_MAX_CHUNKS")) : 32;
+    static const int cap = getenv("RT_AMD_APEX_MAX_CHUNKS") ? atoi(getenv("RT_AMD_APEX_MAX_CHUNKS")) : 64;
     int c = tiles / 8;
     if (c > cap) c = cap;
     return c < 1 ? 1 : c;

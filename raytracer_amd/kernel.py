@@ -102,8 +102,8 @@ def band(H: int, nranks: int, rank: int) -> tuple[int, int]:
 
 def rows_part(H: int, parts: int = 1, part: int = 0, block: int = 16, y0: int = 0,
               y1: int | None = None) -> RtRows:
-    """Row set `part` of `parts` of the rows [y0,y1), interleaved in blocks of `block` rows
-    (rt_rows in include/rt_amd.h).  parts = 1 is the contiguous band."""
+    """Row set `part` of `parts` of the rows [y0,y1), interleaved in blocks of `block` rows dealt
+    forwards and backwards in turn (rt_rows in include/rt_amd.h).  parts = 1 is the contiguous band."""
     return RtRows(y0, H if y1 is None else y1, block, parts, part)
 
 
@@ -117,7 +117,9 @@ def rows_image_rows(r: RtRows) -> np.ndarray:
     """Image row of every local row of the set, ascending."""
     n = rows_count(r)
     lr = np.arange(n)
-    return r.y0 + ((lr // r.block) * r.parts + r.part) * r.block + lr % r.block
+    rnd = lr // r.block
+    slot = np.where(rnd % 2 == 1, r.parts - 1 - r.part, r.part)       # odd rounds are dealt backwards
+    return r.y0 + (rnd * r.parts + slot) * r.block + lr % r.block
 
 
 # ------------------------------------------------------------------ batched API

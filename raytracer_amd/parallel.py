@@ -51,12 +51,13 @@ def assemble_rows(gathered, H: int, world: int):
 
 
 def part_rows(H: int, world: int, rank: int, block: int = 16):
-    """Interleaved row set of `rank`: blocks rank, rank + world, ... of `block` rows."""
+    """Interleaved row set of `rank`: one block of `block` rows out of every `world`, dealt
+    forwards and backwards in turn (rt_rows in include/rt_amd.h)."""
     return kernel.rows_part(H, world, rank, block)
 
 
 def max_part_rows(H: int, world: int, block: int = 16) -> int:
-    return kernel.rows_count(part_rows(H, world, 0, block))      # part 0 is never the shortest
+    return max(kernel.rows_count(part_rows(H, world, r, block)) for r in range(world))
 
 
 def assemble_parts(gathered, H: int, world: int, block: int = 16):
