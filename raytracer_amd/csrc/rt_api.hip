@@ -578,7 +578,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     const double ez = (double)(W / 2) / tan_half;       // driver.c:133
     const double eye[3] = {0, 0, 0};                    // driver.c:121-123
     const double hw = 0.5 * W + 1, hh = 0.5 * H + 1;
-    RT_TRY(rt_launch_pack_apex(sc, eye, ez, sqrt(hw * hw + hh * hh + ez * ez), 0, st));
+    RT_TRY(rt_launch_pack_apex(sc, eye, ez, sqrt(hw * hw + hh * hh + ez * ez), 0, true, st));
 
     SweepArgs a{};
     a.planes = sc->planes_apex.as<float4>(); a.plane_stride = sc->num_tris_padded;
@@ -785,7 +785,7 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows,
         RT_TRY(anyhit_buffers(sc, npix * 3 * (size_t)lights));
         // |D'| <= sqrt(3) for a direction scaled to a unit dominant component
         for (int k = 0; k < lights; ++k)
-            RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l0 + k], 1.0, 1.75, k, st));
+            RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l0 + k], 1.0, 1.75, k, false, st));
         SweepArgs a{};
         a.planes = sc->planes_apex.as<float4>(); a.plane_stride = sc->num_tris_padded;
         a.light_plane_stride = (long)RT_APEX_PLANES * sc->num_tris_padded;

@@ -159,7 +159,7 @@ int rt_launch_pack(rt_scene* sc, hipStream_t st);
 // apex planes for rays through `apex`; zs is folded into the z components (the constant z of
 // pixel-grid directions, 1 otherwise); dmax bounds |D| of every ray of the sweep
 int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, int set,
-                        hipStream_t st);      // into plane set `set` of sc->planes_apex
+                        bool sign_layout, hipStream_t st);      // into plane set `set` of sc->planes_apex
 
 // The pixel rows one call works on: one block of `block` rows out of every `parts` (rt_rows in
 // the public header); parts = 1 is the contiguous band [y0, y0 + rows).  Outputs are indexed by

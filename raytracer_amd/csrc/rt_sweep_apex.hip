@@ -47,6 +47,9 @@
 #ifndef RT_RASTER_UNROLL
 #define RT_RASTER_UNROLL 4
 #endif
+#ifndef RT_RASTER_CHAIN
+#define RT_RASTER_CHAIN 1   // the lane's pixels step along X by additions instead of one FMA each
+#endif
 
 namespace {
 
@@ -60,17 +63,21 @@ __device__ __forceinline__ Tri2 load_tri2(const float4* p) { return {p[0], p[RT_
 // ------------------------------------------------------------------------------------------
 // primary rays on the pixel grid
 // ------------------------------------------------------------------------------------------
+// The rest of the inside test for one pixel that passed the sign tests of triangle `tri`.
+// Xs = the pixel's X / 8, un = its first sign-test value -(U + delta); p = the triangle's plane 0
+// in the LDS tile.
 __device__ __forceinline__ void finish_raster(Book& bk, int32_t* __restrict__ list_slot, int tri,
                                               const Tri2& q, const float4* __restrict__ p,
-                                              float X, float Y, float yu)
+                                              float Xs, float Y, float un)
 {
     const float4 Hh = p[2 * RT_TILE], N = p[3 * RT_TILE];
     const float margin = q.Q.w;
-    if (margin == INF) {            // nearly degenerate triangle: no fp32 verdict
+    if (margin == INF) {            // no fp32 verdict for this triangle (see k_pack_apex)
         if (bk.best_hi != -INF) push(bk, list_slot, tri);
         return;
     }
-    const float U = __builtin_fmaf(X, q.P.x, yu);
+    const float X = 8.0f * Xs;
+    const float U = -un - q.P.w;
     const float V = __builtin_fmaf(X, Hh.x, __builtin_fmaf(Y, Hh.y, Hh.z));
     const float d = __builtin_fmaf(X, N.x, __builtin_fmaf(Y, N.y, N.z));
     const float a = U * d, b = V * d;
@@ -99,14 +106,15 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_raster(const Swee
     // ray number: local pixel, in the segment of this workgroup's triangle chunk
     const long slot0 = (long)blockIdx.y * A.chunk_stride + (long)lr * A.W + px0;
 
-    float X[R];
+    // pixel r of the lane has X = px0 + 8 r - W/2 (driver.c:131); the planes carry 8 p.x, so
+    // the sweep works with X / 8 = Xs0 + r (exact in fp32)
+    const float Xs0 = (float)(px0 - A.W / 2) * 0.125f;
     Book bk[R];
     bool valid[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int px = px0 + 8 * r;
         valid[r] = (px < A.W) && (lr < A.rows.rows);
-        X[r] = (float)(px - A.W / 2);                   // driver.c:131
         bk[r].best = INF;
         bk[r].best_hi = valid[r] ? INF : -INF;
         bk[r].cnt = valid[r] ? 0 : RT_CNT_RETIRED;
@@ -135,24 +143,37 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_raster(const Swee
         for (int j = 0; j < RT_TILE; ++j) {
             const Tri2 cur = next;
             next = load_tri2(base + ((j + 1) & (RT_TILE - 1)));     // last iteration re-reads entry 0 (unused)
+            // sign tests (k_pack_apex, sign layout): un = -(U + delta) and wn = -(W' + delta) of an
+            // orientation-normalised triangle are both negative exactly when the pixel is in the
+            // u slab, allowance included; their sign bits are and-ed per pixel and or-ed over
+            // the lane's pixels
             const float yu = __builtin_fmaf(Y, cur.P.y, cur.P.z);
             const float yw = __builtin_fmaf(Y, cur.Q.y, cur.Q.z);
-            float s[R];
+            float un = __builtin_fmaf(Xs0, cur.P.x, yu);
+            float wn = __builtin_fmaf(Xs0, cur.Q.x, yw);
+            int acc = __float_as_int(un) & __float_as_int(wn);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float U = __builtin_fmaf(X[r], cur.P.x, yu);
-                const float Wp = __builtin_fmaf(X[r], cur.Q.x, yw);
-                s[r] = __builtin_fmaf(U, Wp, cur.P.w);
+            for (int r = 1; r < R; ++r) {
+#if RT_RASTER_CHAIN
+                un += cur.P.x;          // X / 8 grows by one from pixel to pixel
+                wn += cur.Q.x;
+#else
+                un = __builtin_fmaf(Xs0 + (float)r, cur.P.x, yu);
+                wn = __builtin_fmaf(Xs0 + (float)r, cur.Q.x, yw);
+#endif
+                acc = (__float_as_int(un) & __float_as_int(wn)) | acc;      // v_and_or_b32
             }
-            float mx = s[0];
+            if (__builtin_expect(acc < 0, 0)) {
+                // which pixels: evaluated again, each from its own X (not kept in the hot loop)
 #pragma unroll
-            for (int r = 1; r < R; ++r) mx = __builtin_fmaxf(mx, s[r]);     // v_max3_f32 pairs
-            if (__builtin_expect(mx >= 0.0f, 0)) {
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (s[r] >= 0.0f)
+                for (int r = 0; r < R; ++r) {
+                    const float Xs = Xs0 + (float)r;
+                    const float u1 = __builtin_fmaf(Xs, cur.P.x, yu);
+                    const float w1 = __builtin_fmaf(Xs, cur.Q.x, yw);
+                    if ((__float_as_int(u1) & __float_as_int(w1)) < 0)
                         finish_raster(bk[r], A.list + (slot0 + 8 * r) * RT_LIST_K, tri0 + j, cur,
-                                      base + j, X[r], Y, yu);
+                                      base + j, Xs, Y, u1);
+                }
             }
         }
         ++tiles_done;

@@ -116,7 +116,8 @@ __global__ void __launch_bounds__(RT_WG)
 k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
             const int* __restrict__ iA, const int* __restrict__ iB, const int* __restrict__ iC,
             int num_tris, int num_tris_padded, const unsigned* __restrict__ max_bits,
-            double px, double py, double pz, double zs, double dmax, float4* __restrict__ planes)
+            double px, double py, double pz, double zs, double dmax, int sign_layout,
+            float4* __restrict__ planes)
 {
     const int i = blockIdx.x * RT_WG + threadIdx.x;
     if (i >= num_tris_padded) return;
@@ -170,9 +171,9 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
     const double l2 = sqrt(e2x * e2x + e2y * e2y + e2z * e2z);
     const double nn = sqrt(nx * nx + ny * ny + nz * nz);
     if (!(nn > 0.0) || !(l1 > 0.0) || !(l2 > 0.0)) null_tri = true;      // also catches NaN
-    if (null_tri) {
+    if (null_tri) {     // never passes: c = -1 in the product layout, positive constants in the sign layout
 #pragma unroll
-        for (int k = 0; k < RT_APEX_PLANES; ++k) *p[k] = null_entry;
+        for (int k = 0; k < RT_APEX_PLANES; ++k) *p[k] = sign_layout ? make_float4(0, 0, 1.0f, 0) : null_entry;
         return;
     }
     // p = a0 x e2, q = e2 x a1, h = e1 x a0, k = a0.nn -- formed in fp64, rounded once
@@ -193,6 +194,35 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
     double m = 32.0 * delta;
     if (nn <= 9.3132257461547852e-10 * l1 * l2) m = (double)__builtin_huge_valf();     // 2^-30
     const double en = u20 * dmax * nn;
+    if (sign_layout) {
+        // Layout for the pixel-grid sweep, whose rays all leave P (t > 0): a hit has
+        // t = k / det > 0, so det has the sign of k, and so have U and W' (0 <= u <= 1).  With
+        // every vector multiplied by s = sign(k) the u slab is U >= 0 and W' >= 0, which the
+        // sweep reads off two sign bits:
+        //     plane 0 = (-8 s p.x, -s p.y, -s p.z zs - delta, delta)    D.plane0 = -(U + delta)
+        //     plane 1 = (-8 s q.x, -s q.y, -s q.z zs - delta, m)        D.plane1 = -(W' + delta)
+        //     plane 2 = s (h, k)     plane 3 = (s nn, en)
+        // for D = (X / 8, Y, 1).  delta (16 * 2^-24 dmax rho l) covers the rounding of the stored
+        // constants, of the two FMAs and of the seven additions that step along a lane's pixels.
+        // When k is too small for its sign to be trusted (P within rounding of the triangle's
+        // plane, which includes the nearly degenerate triangles) no fp32 verdict is possible and
+        // every pixel passes the triangle on to the exact pass.
+        const bool ambiguous = !(fabs(k) > 9.3132257461547852e-10 * rho * l1 * l2);     // 2^-30
+        if (ambiguous) {
+            *p[0] = make_float4(0, 0, -1.0f, 0);
+            *p[1] = make_float4(0, 0, -1.0f, __builtin_huge_valf());
+            *p[2] = make_float4(0, 0, 0, 0);
+            *p[3] = make_float4(0, 0, 0, 0);
+            return;
+        }
+        const double sg = k < 0.0 ? -1.0 : 1.0;
+        const float df = (float)delta * 1.0000002f;
+        *p[0] = make_float4((float)(-8.0 * sg * ux), (float)(-sg * uy), (float)(-sg * zs * uz - delta), df);
+        *p[1] = make_float4((float)(-8.0 * sg * qx_), (float)(-sg * qy_), (float)(-sg * zs * qz_ - delta), (float)m);
+        *p[2] = make_float4((float)(sg * hx), (float)(sg * hy), (float)(sg * zs * hz), (float)(sg * k));
+        *p[3] = make_float4((float)(sg * nx), (float)(sg * ny), (float)(sg * zs * nz), (float)en * 1.0000002f);
+        return;
+    }
     *p[0] = make_float4((float)ux, (float)uy, (float)(zs * uz), (float)c * 1.0000002f);
     *p[1] = make_float4((float)qx_, (float)qy_, (float)(zs * qz_), (float)m);
     *p[2] = make_float4((float)hx, (float)hy, (float)(zs * hz), (float)k);
@@ -202,7 +232,7 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
 }  // namespace
 
 int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, int set,
-                        hipStream_t st)
+                        bool sign_layout, hipStream_t st)
 {
     const int np = sc->num_tris_padded;
     if (set < 0 || set >= RT_APEX_SETS) {
@@ -213,7 +243,7 @@ int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dm
                        sc->ex.as<double>(), sc->ey.as<double>(), sc->ez.as<double>(),
                        sc->iA.as<int>(), sc->iB.as<int>(), sc->iC.as<int>(), sc->num_tris, np,
                        sc->scratch_max.as<unsigned>(), apex[0], apex[1], apex[2], zs, dmax,
-                       sc->planes_apex.as<float4>() + (size_t)set * RT_APEX_PLANES * np);
+                       sign_layout ? 1 : 0, sc->planes_apex.as<float4>() + (size_t)set * RT_APEX_PLANES * np);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("apex pack launch failed: %s", hipGetErrorString(e));

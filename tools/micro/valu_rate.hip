@@ -1,0 +1,84 @@
+// Issue rate of VALU instructions on gfx950 (development aid): 8 independent chains per wave,
+// 8 waves per SIMD.   hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define REP8(x) x x x x x x x x
+#define KERNEL(name, body)                                                                        \
+    __global__ void __launch_bounds__(256) name(float* out, int iters, float a, float b)         \
+    {                                                                                             \
+        float v0 = threadIdx.x, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3, v4 = v0 + 4, v5 = v0 + 5,  \
+              v6 = v0 + 6, v7 = v0 + 7;                                                            \
+        for (int i = 0; i < iters; ++i)                                                           \
+            asm volatile(REP8(body)                                                               \
+                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6),  \
+                           "+v"(v7)                                                               \
+                         : "v"(a), "v"(b) : "vcc");                                               \
+        out[blockIdx.x * 256 + threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;              \
+    }
+KERNEL(k_fma, "v_fma_f32 %0, %0, %8, %9\n" "v_fma_f32 %1, %1, %8, %9\n" "v_fma_f32 %2, %2, %8, %9\n" "v_fma_f32 %3, %3, %8, %9\n" "v_fma_f32 %4, %4, %8, %9\n" "v_fma_f32 %5, %5, %8, %9\n" "v_fma_f32 %6, %6, %8, %9\n" "v_fma_f32 %7, %7, %8, %9\n" )
+KERNEL(k_mul, "v_mul_f32 %0, %0, %8\n" "v_mul_f32 %1, %1, %8\n" "v_mul_f32 %2, %2, %8\n" "v_mul_f32 %3, %3, %8\n" "v_mul_f32 %4, %4, %8\n" "v_mul_f32 %5, %5, %8\n" "v_mul_f32 %6, %6, %8\n" "v_mul_f32 %7, %7, %8\n" )
+KERNEL(k_add, "v_add_f32 %0, %0, %8\n" "v_add_f32 %1, %1, %8\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %8\n" "v_add_f32 %4, %4, %8\n" "v_add_f32 %5, %5, %8\n" "v_add_f32 %6, %6, %8\n" "v_add_f32 %7, %7, %8\n" )
+KERNEL(k_mac, "v_fmac_f32 %0, %8, %9\n" "v_fmac_f32 %1, %8, %9\n" "v_fmac_f32 %2, %8, %9\n" "v_fmac_f32 %3, %8, %9\n" "v_fmac_f32 %4, %8, %9\n" "v_fmac_f32 %5, %8, %9\n" "v_fmac_f32 %6, %8, %9\n" "v_fmac_f32 %7, %8, %9\n" )
+KERNEL(k_and, "v_and_b32 %0, %0, %8\n" "v_and_b32 %1, %1, %8\n" "v_and_b32 %2, %2, %8\n" "v_and_b32 %3, %3, %8\n" "v_and_b32 %4, %4, %8\n" "v_and_b32 %5, %5, %8\n" "v_and_b32 %6, %6, %8\n" "v_and_b32 %7, %7, %8\n" )
+KERNEL(k_or3, "v_or3_b32 %0, %0, %8, %9\n" "v_or3_b32 %1, %1, %8, %9\n" "v_or3_b32 %2, %2, %8, %9\n" "v_or3_b32 %3, %3, %8, %9\n" "v_or3_b32 %4, %4, %8, %9\n" "v_or3_b32 %5, %5, %8, %9\n" "v_or3_b32 %6, %6, %8, %9\n" "v_or3_b32 %7, %7, %8, %9\n" )
+KERNEL(k_and_or, "v_and_or_b32 %0, %0, %8, %9\n" "v_and_or_b32 %1, %1, %8, %9\n" "v_and_or_b32 %2, %2, %8, %9\n" "v_and_or_b32 %3, %3, %8, %9\n" "v_and_or_b32 %4, %4, %8, %9\n" "v_and_or_b32 %5, %5, %8, %9\n" "v_and_or_b32 %6, %6, %8, %9\n" "v_and_or_b32 %7, %7, %8, %9\n" )
+KERNEL(k_max3, "v_max3_f32 %0, %0, %8, %9\n" "v_max3_f32 %1, %1, %8, %9\n" "v_max3_f32 %2, %2, %8, %9\n" "v_max3_f32 %3, %3, %8, %9\n" "v_max3_f32 %4, %4, %8, %9\n" "v_max3_f32 %5, %5, %8, %9\n" "v_max3_f32 %6, %6, %8, %9\n" "v_max3_f32 %7, %7, %8, %9\n" )
+KERNEL(k_max, "v_max_f32 %0, %0, %8\n" "v_max_f32 %1, %1, %8\n" "v_max_f32 %2, %2, %8\n" "v_max_f32 %3, %3, %8\n" "v_max_f32 %4, %4, %8\n" "v_max_f32 %5, %5, %8\n" "v_max_f32 %6, %6, %8\n" "v_max_f32 %7, %7, %8\n" )
+KERNEL(k_min, "v_min_f32 %0, %0, %8\n" "v_min_f32 %1, %1, %8\n" "v_min_f32 %2, %2, %8\n" "v_min_f32 %3, %3, %8\n" "v_min_f32 %4, %4, %8\n" "v_min_f32 %5, %5, %8\n" "v_min_f32 %6, %6, %8\n" "v_min_f32 %7, %7, %8\n" )
+KERNEL(k_max_i32, "v_max_i32 %0, %0, %8\n" "v_max_i32 %1, %1, %8\n" "v_max_i32 %2, %2, %8\n" "v_max_i32 %3, %3, %8\n" "v_max_i32 %4, %4, %8\n" "v_max_i32 %5, %5, %8\n" "v_max_i32 %6, %6, %8\n" "v_max_i32 %7, %7, %8\n" )
+KERNEL(k_max3_i32, "v_max3_i32 %0, %0, %8, %9\n" "v_max3_i32 %1, %1, %8, %9\n" "v_max3_i32 %2, %2, %8, %9\n" "v_max3_i32 %3, %3, %8, %9\n" "v_max3_i32 %4, %4, %8, %9\n" "v_max3_i32 %5, %5, %8, %9\n" "v_max3_i32 %6, %6, %8, %9\n" "v_max3_i32 %7, %7, %8, %9\n" )
+KERNEL(k_add_u32, "v_add_u32 %0, %0, %8\n" "v_add_u32 %1, %1, %8\n" "v_add_u32 %2, %2, %8\n" "v_add_u32 %3, %3, %8\n" "v_add_u32 %4, %4, %8\n" "v_add_u32 %5, %5, %8\n" "v_add_u32 %6, %6, %8\n" "v_add_u32 %7, %7, %8\n" )
+KERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %8, vcc\n" "v_cndmask_b32 %1, %1, %8, vcc\n" "v_cndmask_b32 %2, %2, %8, vcc\n" "v_cndmask_b32 %3, %3, %8, vcc\n" "v_cndmask_b32 %4, %4, %8, vcc\n" "v_cndmask_b32 %5, %5, %8, vcc\n" "v_cndmask_b32 %6, %6, %8, vcc\n" "v_cndmask_b32 %7, %7, %8, vcc\n" )
+KERNEL(k_cmp, "v_cmp_ge_f32 vcc, %0, %8\n" "v_cmp_ge_f32 vcc, %1, %8\n" "v_cmp_ge_f32 vcc, %2, %8\n" "v_cmp_ge_f32 vcc, %3, %8\n" "v_cmp_ge_f32 vcc, %4, %8\n" "v_cmp_ge_f32 vcc, %5, %8\n" "v_cmp_ge_f32 vcc, %6, %8\n" "v_cmp_ge_f32 vcc, %7, %8\n" )
+KERNEL(k_mix_2fma_andor, "v_fma_f32 %0, %0, %8, %9\n" "v_fma_f32 %1, %1, %8, %9\n" "v_and_or_b32 %2, %0, %1, %2\n" "v_fma_f32 %3, %3, %8, %9\n" "v_fma_f32 %4, %4, %8, %9\n" "v_and_or_b32 %5, %3, %4, %5\n" "v_fma_f32 %6, %6, %8, %9\n" "v_fma_f32 %7, %7, %8, %9\n" )
+KERNEL(k_mix_6fma_max3, "v_fma_f32 %0, %0, %8, %9\n" "v_fma_f32 %1, %1, %8, %9\n" "v_fma_f32 %2, %2, %8, %9\n" "v_fma_f32 %3, %3, %8, %9\n" "v_fma_f32 %4, %4, %8, %9\n" "v_fma_f32 %5, %5, %8, %9\n" "v_max3_f32 %6, %6, %2, %5\n" "v_fma_f32 %7, %7, %8, %9\n" )
+KERNEL(k_mix_fma_and, "v_fma_f32 %0, %0, %8, %9\n" "v_and_b32 %1, %1, %8\n" "v_fma_f32 %2, %2, %8, %9\n" "v_and_b32 %3, %3, %8\n" "v_fma_f32 %4, %4, %8, %9\n" "v_and_b32 %5, %5, %8\n" "v_fma_f32 %6, %6, %8, %9\n" "v_and_b32 %7, %7, %8\n" )
+KERNEL(k_mix_fma_add, "v_fma_f32 %0, %0, %8, %9\n" "v_add_f32 %1, %1, %8\n" "v_fma_f32 %2, %2, %8, %9\n" "v_add_f32 %3, %3, %8\n" "v_fma_f32 %4, %4, %8, %9\n" "v_add_f32 %5, %5, %8\n" "v_fma_f32 %6, %6, %8, %9\n" "v_add_f32 %7, %7, %8\n" )
+
+template <class K>
+void run(const char* name, K k, float* out, int wgs)
+{
+    const int iters = 40000;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k, dim3(wgs), dim3(256), 0, 0, out, iters / 4, 1.0001f, 0.5f);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(wgs), dim3(256), 0, 0, out, iters, 1.0001f, 0.5f);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double instr = (double)wgs * 4 * iters * 64;     // wave instructions
+    printf("%-16s %8.3f ms  %.3e wave-instr/s  cycles per wave-instr per SIMD at 2.4 GHz: %.2f\n", name, ms,
+           instr / (ms * 1e-3), 2.4e9 * 1024 / (instr / (ms * 1e-3)));
+}
+
+int main()
+{
+    float* out;
+    const int wgs = 256 * 8;    // 8 workgroups = 32 waves per CU = 8 per SIMD
+    (void)hipMalloc(&out, sizeof(float) * 256 * wgs);
+    run("fma", k_fma, out, wgs);
+    run("fma", k_fma, out, wgs);
+    run("mul", k_mul, out, wgs);
+    run("add", k_add, out, wgs);
+    run("mac", k_mac, out, wgs);
+    run("and", k_and, out, wgs);
+    run("or3", k_or3, out, wgs);
+    run("and_or", k_and_or, out, wgs);
+    run("max3", k_max3, out, wgs);
+    run("max", k_max, out, wgs);
+    run("min", k_min, out, wgs);
+    run("max_i32", k_max_i32, out, wgs);
+    run("max3_i32", k_max3_i32, out, wgs);
+    run("add_u32", k_add_u32, out, wgs);
+    run("cndmask", k_cndmask, out, wgs);
+    run("cmp", k_cmp, out, wgs);
+    run("mix_2fma_andor", k_mix_2fma_andor, out, wgs);
+    run("mix_6fma_max3", k_mix_6fma_max3, out, wgs);
+    run("mix_fma_and", k_mix_fma_and, out, wgs);
+    run("mix_fma_add", k_mix_fma_add, out, wgs);
+    (void)hipFree(out);
+    return 0;
+}

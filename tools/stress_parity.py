@@ -151,6 +151,7 @@ if __name__ == "__main__":
     t00 = time.time()
     bad, n, h = run(a.seeds, a.rays)
     print(f"TOTAL mismatches {bad} of {n} rays ({h} hits)  ({time.time()-t00:.0f} s)")
-    bh, br, px, hp = run_frames(a.seeds)
-    print(f"FRAMES: hit/tuv mismatches {bh}, rgb8 off by more than 1: {br}, of {px} pixels ({hp} hit)  "
-          f"({time.time()-t00:.0f} s)")
+    for W, H in ((128, 96), (1000, 40)):       # the second: long pixel rows for the sweep that steps along X
+        bh, br, px, hp = run_frames(a.seeds, W, H)
+        print(f"FRAMES {W}x{H}: hit/tuv mismatches {bh}, rgb8 off by more than 1: {br}, of {px} pixels ({hp} hit)  "
+              f"({time.time()-t00:.0f} s)")
