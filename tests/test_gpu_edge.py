@@ -246,3 +246,58 @@ def test_far_ray_origins(dist):
     hit = hit.cpu().numpy()
     assert sum(int(hit[k] != O.intersect(osc, S[k], E[k])[0]) for k in range(500)) == 0
     sc.close()
+
+
+def _eye_space_mesh(tris):
+    """Mesh from a list of triangles given directly in eye space (used with an identity obmat)."""
+    P = np.vstack([np.zeros((1, 3))] + [np.asarray(t, float) for t in tris])
+    n = len(tris)
+    A = np.arange(1, 3 * n + 1, 3, dtype=np.int32)
+    nrm = np.vstack([np.zeros((1, 3))] + [np.cross(np.subtract(t[1], t[0]), np.subtract(t[2], t[0]))[None] for t in tris])
+    idn = np.arange(1, n + 1, dtype=np.int32)
+    return scenes.Mesh(x=P[:, 0].copy(), y=P[:, 1].copy(), z=P[:, 2].copy(), xn=nrm[:, 0].copy(),
+                       yn=nrm[:, 1].copy(), zn=nrm[:, 2].copy(), A=A, B=A + 1, C=A + 2,
+                       An=idn, Bn=idn.copy(), Cn=idn.copy())
+
+
+@pytest.mark.parametrize("through_eye", [3, 40])     # 40: more than a candidate list holds
+def test_triangles_whose_plane_contains_the_eye(through_eye):
+    """The pixel-grid sweep decides a pair from sign bits after orienting every triangle towards
+    the eye (t > 0 fixes the sign of the determinant, triangle_intersection.cu:59-94).  A
+    triangle seen exactly or almost edge-on has no orientation: it must be left to the fp64
+    pass, together with triangles behind the eye and across the eye plane, without disturbing
+    the ordinary ones."""
+    rng = np.random.default_rng(through_eye)
+    tris = []
+    for k in range(30):             # ordinary triangles in front of the eye, both windings
+        c = np.array([rng.uniform(-6, 6), rng.uniform(-4, 4), rng.uniform(10, 30)])
+        e1, e2 = rng.normal(size=3) * 2, rng.normal(size=3) * 2
+        tris.append([c, c + e1, c + e2] if k % 2 else [c, c + e2, c + e1])
+    for k in range(through_eye):    # planes through the eye (the origin of eye space), or 1e-13 off it
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        b1 = np.cross(n, [0.3, 0.5, 0.8]); b1 /= np.linalg.norm(b1)
+        b2 = np.cross(n, b1)
+        off = n * (1e-13 if k % 3 == 0 else 0.0)
+        c = b1 * rng.uniform(-8, 8) + b2 * rng.uniform(-8, 8)
+        if k % 4 == 0:
+            c = c * 0.01            # the eye inside or next to the triangle
+        tris.append([c + off, c + 3 * b1 + off, c + 3 * b2 + off])
+    for k in range(6):              # behind the eye, and across the eye plane z = 0
+        c = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), -5.0 if k < 3 else 0.0])
+        tris.append([c + [0, 0, -1], c + [2, 0, 1.5], c + [0, 2, 1.5]])
+    order = rng.permutation(len(tris))
+    mesh = _eye_space_mesh([tris[i] for i in order])
+    fr = kernel.driver_frame(0)
+    for r in range(4):
+        for c in range(4):
+            fr.obmat[r][c] = fr.obinv[r][c] = 1.0 if r == c else 0.0
+    W, H = 96, 64
+    ref, _ = _ref(mesh, fr, W, H)
+    sc, out = _gpu(mesh, fr, W, H)
+    assert (ref["hit"] >= 0).mean() > 0.05
+    assert np.array_equal(out["hit"], ref["hit"])
+    m = ref["hit"] >= 0
+    assert np.array_equal(out["tuv"][m], ref["tuv"][m])
+    assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    sc.close()
