@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 TAN_HALF = math.tan(30 * math.pi / 180)          # driver.c:22,25
 F_TEST = 46.0                                    # fp32 flop per general Moller-Trumbore test
 PEAK_FP32_TFLOPS = 157.3                         # MI355X vector fp32 (256 CU x 256 flop/clk x 2.4 GHz)
+PEAK_VALU_TINSTR = PEAK_FP32_TFLOPS / 2          # VALU lane-instructions/s: the same issue slots, one FMA = 2 flop
 
 WORKLOADS = {
     # name: (mesh kind, triangles, W, H)
@@ -237,6 +238,11 @@ def main() -> None:
                                          C.byref(f_shadow), C.byref(chunks))
         f_exec = f_primary.value
         achieved = nominal * f_exec / F_TEST      # flops the hot loop really executes
+        mix = [C.c_int() for _ in range(5)]
+        _lib.load().rt_raster_sweep_mix(*[C.byref(m) for m in mix])
+        mix_ppl, n_fma, n_add, n_logic, n_cmp = [m.value for m in mix]
+        instr_per_test = (n_fma + n_add + n_logic + n_cmp) / mix_ppl
+        tests_per_s_launch = tests_per_launch / (sweep_ms_avg * 1e-3) if sweep_ms_avg > 0 else 0.0
         traffic = measured_traffic(args.workload, f"raster-tile{tile.value}-ppl{ppl.value}-chunks{chunks.value}") if world == 1 else None
         res = {
             "metric": "Mrays/s and ray-tri tests/s (% fp32 peak) at 1/2/4/8 MI355X vs host-CPU ref",
@@ -265,17 +271,27 @@ def main() -> None:
             "shadow_sweeps_rank0": {"ms_per_frame": prof.shadow_ms / steps,
                                     "tests_per_frame": prof.shadow_tests / steps,
                                     "launches_per_frame": prof.shadow_launches / steps},
-            # Roofline of the dominant kernel.  `achieved` prices a ray-triangle pair at the fp32
-            # flops the hot loop executes for it (rocprof SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 agree
-            # within 2 %, see profiles/), because the kernel uses the shared origin of the primary
-            # rays, shares arithmetic between the pixels of a lane and evaluates the test lazily.
+            # Roofline of the dominant kernel, the closest-hit sweep of the primary rays.  It is a
+            # vector-ALU kernel: `achieved` counts the fp32 flops its hot loop executes per
+            # ray-triangle pair (FMA = 2, addition = 1; rocprof SQ_INSTS_VALU_{ADD,MUL,FMA}_F32
+            # agree, see profiles/) against the fp32 vector peak.  What actually bounds the loop is
+            # instruction issue (one VALU instruction per SIMD every two cycles, whatever it
+            # computes): most of its arithmetic is additions that step a plane distance from one
+            # pixel of a lane to the next, so `valu_issue` is the figure that says how close the
+            # kernel is to the machine's limit.
             "roofline": {
                 "bound": "valu-fp32", "kernel": "k_sweep_raster (primary rays, closest hit)",
                 "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS,
                 "avg_launch_ms": sweep_ms_avg, "tests_per_launch": tests_per_launch,
-                "tests_per_s": tests_per_launch / (sweep_ms_avg * 1e-3) if sweep_ms_avg > 0 else 0.0,
+                "tests_per_s": tests_per_s_launch,
                 "flop_per_test": f_exec,
+                "valu_issue": {"instr_per_test": instr_per_test,
+                               "per_lane_and_triangle": {"pixels": mix_ppl, "fma": n_fma, "add": n_add,
+                                                         "logic": n_logic, "compare": n_cmp},
+                               "achieved": tests_per_s_launch * instr_per_test / 1e12,
+                               "peak": PEAK_VALU_TINSTR, "unit": "T lane-instr/s",
+                               "frac": tests_per_s_launch * instr_per_test / 1e12 / PEAK_VALU_TINSTR},
                 "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
                 # the 46 flop of a general Moller-Trumbore test with its divisions, for reference only:

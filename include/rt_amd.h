@@ -218,6 +218,12 @@ int rt_sweep_config(int* form, int* tile_tris, int* rays_per_lane, int* flop_per
 int rt_apex_sweep_config(int* tile_tris, int* primary_pixels_per_lane,
                          double* primary_flop_per_pair, int* shadow_rays_per_lane,
                          double* shadow_flop_per_pair, int* primary_chunks);
+/* VALU instructions of the pixel-grid sweep's hot loop per lane and triangle, i.e. per
+ * *pixels_per_lane pixel-triangle pairs (of the most recent primary sweep): fp32 FMAs, fp32
+ * additions, 32-bit logic instructions and compares.  The loop is bound by instruction issue,
+ * not by flops: most of its arithmetic is additions that step a plane distance from one pixel
+ * of the lane to the next. */
+int rt_raster_sweep_mix(int* pixels_per_lane, int* fma, int* add, int* logic, int* compare);
 int rt_profile_enable(int on);     /* wraps sweep launches in HIP events and reads the device
                                       counters back (adds a sync per launch); the ray and
                                       candidate counts above are only collected while on */

@@ -105,6 +105,18 @@ extern "C" int rt_apex_sweep_config(int* tile_tris, int* primary_pixels_per_lane
     return RT_OK;
 }
 
+extern "C" int rt_raster_sweep_mix(int* pixels_per_lane, int* fma, int* add, int* logic, int* compare)
+{
+    const int rpl = rt_g().last_raster_rpl > 0 ? rt_g().last_raster_rpl : RT_RASTER_RPL;
+    const RasterMix m = rt_raster_mix(rpl);
+    if (pixels_per_lane) *pixels_per_lane = rpl;
+    if (fma) *fma = m.fma;
+    if (add) *add = m.add;
+    if (logic) *logic = m.logic;
+    if (compare) *compare = m.compare;
+    return RT_OK;
+}
+
 extern "C" int rt_profile_enable(int on) { rt_g().profiling = on != 0; return RT_OK; }
 extern "C" int rt_profile_reset(void) { rt_g().prof = rt_profile{}; return RT_OK; }
 extern "C" int rt_profile_get(rt_profile* out)

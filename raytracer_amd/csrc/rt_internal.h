@@ -66,10 +66,15 @@ constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
 constexpr int RT_APEX_PLANES = 4;
 constexpr int RT_APEX_LIGHTS = 4;   // lights swept per any-hit launch (plane sets kept side by side)
 constexpr int RT_APEX_SETS = 3 * RT_APEX_LIGHTS;    // ray sets per launch: light x dominant axis
-// fp32 flops per pair in the hot loops (FMA = 2).  Pixel-grid sweep, per lane and triangle:
-// 2 row terms + 2 FMA per pixel for the two plane distances + 1 FMA per pixel for the
-// slab product.  Apex sweep: two dot products with a unit dominant component (2 FMA each) + 1 FMA.
-constexpr double rt_raster_flop_per_pair(int rpl) { return (2.0 * 2 + rpl * 3 * 2.0) / rpl; }
+// Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels): 2 FMA for the row terms,
+// 2 FMA for the first pixel, 2 additions for each further pixel, then per pixel one logic
+// instruction on the two sign bits, and one compare.  Apex sweep, per pair: two dot products
+// with a unit dominant component (2 FMA each) + 1 FMA.
+struct RasterMix { int fma, add, logic, compare; };
+constexpr RasterMix rt_raster_mix(int rpl) { return RasterMix{4, 2 * (rpl - 1), rpl, 1}; }
+// fp32 flops per pair (FMA = 2) and VALU instructions per pair of that loop
+constexpr double rt_raster_flop_per_pair(int rpl) { return (2.0 * 4 + 2.0 * (rpl - 1)) / rpl; }
+constexpr double rt_raster_instr_per_pair(int rpl) { return (4.0 + 2.0 * (rpl - 1) + rpl + 1.0) / rpl; }
 constexpr double RT_APEX_FLOP_PER_PAIR = 10.0;
 
 // per-ray candidate counter written by the sweep: low bits = candidates pushed, plus

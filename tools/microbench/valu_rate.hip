@@ -35,6 +35,24 @@ KERNEL(k_mix_6fma_max3, "v_fma_f32 %0, %0, %8, %9\n" "v_fma_f32 %1, %1, %8, %9\n
 KERNEL(k_mix_fma_and, "v_fma_f32 %0, %0, %8, %9\n" "v_and_b32 %1, %1, %8\n" "v_fma_f32 %2, %2, %8, %9\n" "v_and_b32 %3, %3, %8\n" "v_fma_f32 %4, %4, %8, %9\n" "v_and_b32 %5, %5, %8\n" "v_fma_f32 %6, %6, %8, %9\n" "v_and_b32 %7, %7, %8\n" )
 KERNEL(k_mix_fma_add, "v_fma_f32 %0, %0, %8, %9\n" "v_add_f32 %1, %1, %8\n" "v_fma_f32 %2, %2, %8, %9\n" "v_add_f32 %3, %3, %8\n" "v_fma_f32 %4, %4, %8, %9\n" "v_add_f32 %5, %5, %8\n" "v_fma_f32 %6, %6, %8, %9\n" "v_add_f32 %7, %7, %8\n" )
 
+#define KERNEL2(name, body)                                                                       \
+    __global__ void __launch_bounds__(256) name(float* out, int iters, float a, float b)         \
+    {                                                                                             \
+        typedef float f2 __attribute__((ext_vector_type(2)));                                     \
+        f2 v0 = {(float)threadIdx.x, 1}, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3, v4 = v0 + 4,     \
+           v5 = v0 + 5, v6 = v0 + 6, v7 = v0 + 7, va = {a, a}, vb = {b, b};                       \
+        for (int i = 0; i < iters; ++i)                                                           \
+            asm volatile(REP8(body)                                                               \
+                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6),  \
+                           "+v"(v7)                                                               \
+                         : "v"(va), "v"(vb));                                                     \
+        f2 s = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;                                             \
+        out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y;                                          \
+    }
+KERNEL2(k_pk_add, "v_pk_add_f32 %0, %0, %8\n" "v_pk_add_f32 %1, %1, %8\n" "v_pk_add_f32 %2, %2, %8\n" "v_pk_add_f32 %3, %3, %8\n" "v_pk_add_f32 %4, %4, %8\n" "v_pk_add_f32 %5, %5, %8\n" "v_pk_add_f32 %6, %6, %8\n" "v_pk_add_f32 %7, %7, %8\n" )
+KERNEL2(k_pk_fma, "v_pk_fma_f32 %0, %0, %8, %9\n" "v_pk_fma_f32 %1, %1, %8, %9\n" "v_pk_fma_f32 %2, %2, %8, %9\n" "v_pk_fma_f32 %3, %3, %8, %9\n" "v_pk_fma_f32 %4, %4, %8, %9\n" "v_pk_fma_f32 %5, %5, %8, %9\n" "v_pk_fma_f32 %6, %6, %8, %9\n" "v_pk_fma_f32 %7, %7, %8, %9\n" )
+KERNEL2(k_pk_mul, "v_pk_mul_f32 %0, %0, %8\n" "v_pk_mul_f32 %1, %1, %8\n" "v_pk_mul_f32 %2, %2, %8\n" "v_pk_mul_f32 %3, %3, %8\n" "v_pk_mul_f32 %4, %4, %8\n" "v_pk_mul_f32 %5, %5, %8\n" "v_pk_mul_f32 %6, %6, %8\n" "v_pk_mul_f32 %7, %7, %8\n" )
+
 template <class K>
 void run(const char* name, K k, float* out, int wgs)
 {
@@ -79,6 +97,10 @@ int main()
     run("mix_6fma_max3", k_mix_6fma_max3, out, wgs);
     run("mix_fma_and", k_mix_fma_and, out, wgs);
     run("mix_fma_add", k_mix_fma_add, out, wgs);
+    run("pk_add", k_pk_add, out, wgs);
+    run("pk_fma", k_pk_fma, out, wgs);
+    run("pk_mul", k_pk_mul, out, wgs);
+    run("add", k_add, out, wgs);
     (void)hipFree(out);
     return 0;
 }
