@@ -698,10 +698,17 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
         a.total_rays = total;
         a.lights = sets;
         a.light_ray_stride = stride;
+        const double ms0 = rt_g().prof.shadow_ms;
+        const uint64_t tests0 = rt_g().prof.shadow_tests;
         RT_TRY(timed_sweep([&] { return launch(a); }, true, 0, a.tests));
-        if (getenv("RT_AMD_TRACE_PASSES"))
-            fprintf(stderr, "rt_amd: any-hit range [%d,%d) over %d set(s), %ld rays, largest %d\n", begin,
-                    end, sets, total, indexed ? live : n);
+        if (getenv("RT_AMD_TRACE_PASSES")) {
+            const double ms = rt_g().prof.shadow_ms - ms0;
+            const double tests = (double)(rt_g().prof.shadow_tests - tests0);
+            fprintf(stderr, "rt_amd: any-hit range [%d,%d) over %d set(s), %ld rays, largest %d: %.3f ms, "
+                            "%.3e tests (%.0f%% of rays x triangles), %.2e tests/s\n", begin, end, sets, total,
+                    indexed ? live : n, ms, tests, 100.0 * tests / ((double)total * (end - begin) + 1e-9),
+                    ms > 0 ? tests / (ms * 1e-3) : 0.0);
+        }
         begin = end;
         if (begin >= np) break;
         // compact the survivors (from the full set the first time in the unbinned case)
@@ -812,25 +819,33 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows,
         auto sweep = [&](const SweepArgs& r) { return rt_launch_sweep_apex(r, st); };
         RT_HIP(hipMemsetAsync(sc->ws_live.p, 0, sizeof(int) * 3 * RT_APEX_SETS, st));
         if (!use_cache) {
-            RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, 0, act0, live0, st));
+            RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, 1, 0, act0, live0, st));
             RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
             continue;
         }
-        // Occluder cache (k_try_cached): the rays of every 4th pixel in x and y first ...
+        // Occluder cache (k_try_cached), coarse to fine: the rays of every 4th pixel in x and y
+        // are swept first; then all the others try the occluders found around them and what is
+        // left of them is swept.
         RT_TRY(sc->ws_act2.reserve(sizeof(int32_t) * npix * (size_t)sets));
         int32_t* act2 = sc->ws_act2.as<int32_t>();
         int* live2 = live0 + 2 * RT_APEX_SETS;
-        a.occ_id = sc->ws_occid.as<int32_t>() + npix * (size_t)l0;
-        RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, 1, act0, live0, st));
-        RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, 2, act2, live2, st));
-        RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
-        // ... then every other ray tries the occluders found around it, and what is left is swept
-        RT_TRY(rt_launch_try_cached(exact_of(sc), a.S, a.E, act2, live2, sets, (int)npix, (long)npix, W,
-                                    nrows, a.cnt, a.occ_id, st));
-        RT_HIP(hipMemsetAsync(live0, 0, sizeof(int) * RT_APEX_SETS, st));
-        RT_TRY(rt_launch_compact(a.cnt, act2, live2, (int)npix, sets, (long)npix, 3, act0, live0, st));
-        a.occ_id = nullptr;
-        RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
+        int32_t* occ_id = sc->ws_occid.as<int32_t>() + npix * (size_t)l0;
+        for (int level = 0; level < RT_SHADOW_LEVELS; ++level) {
+            const int step = RT_SHADOW_STEPS[level];
+            const bool record = level + 1 < RT_SHADOW_LEVELS;       // the next level reads what this one finds
+            a.occ_id = record ? occ_id : nullptr;
+            RT_HIP(hipMemsetAsync(live0, 0, sizeof(int) * 3 * RT_APEX_SETS, st));
+            if (level == 0) {
+                RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, step, 0, act0, live0, st));
+            } else {
+                const int coarser = RT_SHADOW_STEPS[level - 1];
+                RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, step, coarser, act2, live2, st));
+                RT_TRY(rt_launch_try_cached(exact_of(sc), a.S, a.E, act2, live2, sets, (int)npix, (long)npix,
+                                            W, nrows, coarser, record, a.cnt, occ_id, st));
+                RT_TRY(rt_launch_compact(a.cnt, act2, live2, (int)npix, sets, (long)npix, 3, act0, live0, st));
+            }
+            RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
+        }
     }
     return resolve_rays(sc, (int)(npix * (size_t)L), S, E, true, nullptr, nullptr, nullptr, occ);
 }

@@ -356,15 +356,17 @@ k_overflow_merge(RAYS rays, const int32_t* __restrict__ ovf, const int* __restri
 
 // Occluder cache of the shadow pass.  Shadow rays of neighbouring pixels towards the same light
 // are nearly parallel and start close together, so whatever occludes one very often occludes
-// the next.  The rays of every RT_SHADOW_SAMPLE-th pixel in x and y are swept first; every other
-// ray then tries the (up to four) triangles that occluded the sample rays around it with the
-// reference's exact test, and only the rays that are still open go through the sweep.  An
-// any-hit query (light_model.c:70 asks whether ANY triangle is hit at dist > 0) does not depend
-// on the order in which triangles are tried, so the result is unchanged.
+// the next.  The rays of a coarse grid of pixels (every `step`-th in x and y) are settled first
+// and record the triangle that occludes them; every ray of the next finer level then tries the
+// (up to RT_SHADOW_NEIGHBOURS squared) triangles recorded around it with the reference's exact test, records the one
+// that occludes it (`record`, for the level after it), and only the rays that are still open
+// go through the sweep.  An any-hit query (light_model.c:70 asks whether ANY triangle is hit at
+// dist > 0) does not depend on the order in which triangles are tried, so the result is
+// unchanged.
 __global__ void __launch_bounds__(RT_WG)
 k_try_cached(ExactScene es, const double* __restrict__ Sa, const double* __restrict__ Ea,
              const int32_t* __restrict__ lists, const int* __restrict__ counts, long stride, int W,
-             int rows, int32_t* __restrict__ cnt, int32_t* __restrict__ occ_id)
+             int rows, int step, int record, int32_t* __restrict__ cnt, int32_t* __restrict__ occ_id)
 {
     const long set = blockIdx.y, light = set / 3;
     const int n = counts[set];
@@ -376,24 +378,29 @@ k_try_cached(ExactScene es, const double* __restrict__ Sa, const double* __restr
     for (long j = (long)blockIdx.x * RT_WG + threadIdx.x; j < n; j += (long)gridDim.x * RT_WG) {
         const int id = lists[j];
         const int px = id % W, lr = id / W;
-        const int sx = px - px % RT_SHADOW_SAMPLE, sy = lr - lr % RT_SHADOW_SAMPLE;
+        const int sx = px - px % step, sy = lr - lr % step;
         const double S[3] = {Sa[3 * (long)id], Sa[3 * (long)id + 1], Sa[3 * (long)id + 2]};
         const double E[3] = {Ea[3 * (long)id], Ea[3 * (long)id + 1], Ea[3 * (long)id + 2]};
-        int tried[4] = {-1, -1, -1, -1};
+        constexpr int NB = RT_SHADOW_NEIGHBOURS, NB2 = NB * NB, LO = (NB - 2) / 2;
+        int tried[NB2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int qx = sx + (k & 1) * RT_SHADOW_SAMPLE, qy = sy + (k >> 1) * RT_SHADOW_SAMPLE;
-            if (qx >= W || qy >= rows) continue;
+        for (int k = 0; k < NB2; ++k) tried[k] = -1;
+#pragma unroll
+        for (int k = 0; k < NB2; ++k) {
+            const int kx = k % NB, ky = k / NB;
+            const int qx = sx + (kx - LO) * step, qy = sy + (ky - LO) * step;
+            if (qx < 0 || qy < 0 || qx >= W || qy >= rows) continue;
             const int t = occ_id[(long)qy * W + qx];
             if (t < 0 || t >= es.num_tris) continue;
             bool seen = false;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) seen = seen || (m < k && tried[m] == t);
+            for (int m = 0; m < NB2; ++m) seen = seen || (m < k && tried[m] == t);
             if (seen) continue;
             tried[k] = t;
             double u, v;
             if (exact_tri(es, t, S, E, u, v) > 0) {        // triangle_intersection.cu:169
                 atomicOr(&cnt[id], RT_CNT_OCCLUDED);
+                if (record) occ_id[id] = t;
                 break;
             }
         }
@@ -545,13 +552,13 @@ int rt_launch_overflow_rays(const ExactScene& es, const double* S, const double*
 
 int rt_launch_try_cached(const ExactScene& es, const double* S, const double* E, const int32_t* lists,
                          const int* counts, int sets, int n_max, long stride, int W, int rows,
-                         int32_t* cnt, int32_t* occ_id, hipStream_t st)
+                         int step, bool record, int32_t* cnt, int32_t* occ_id, hipStream_t st)
 {
     if (n_max <= 0 || sets <= 0) return RT_OK;
     long wgs = ((long)n_max + RT_WG - 1) / RT_WG;
     if (wgs > 4096) wgs = 4096;
     hipLaunchKernelGGL(k_try_cached, dim3((unsigned)wgs, sets), dim3(RT_WG), 0, st, es, S, E, lists, counts,
-                       stride, W, rows, cnt, occ_id);
+                       stride, W, rows, step, record ? 1 : 0, cnt, occ_id);
     return launched("try_cached");
 }
 

@@ -228,11 +228,20 @@ constexpr int RT_RASTER_MAX_CHUNKS = 24;
 void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks);
 int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st);     // any-hit over binned ray lists
 // shadow rays [light][pixel] -> ray-number lists per (light, dominant axis), stride entries apart
-// which = 0: every ray; 1: only the rays of pixels whose column and local row are multiples of
-// RT_SHADOW_SAMPLE (the sample rays of the occluder cache); 2: all the others
+// Only the rays of pixels whose column and local row are multiples of step_in, and not both
+// multiples of step_out (0: no exclusion): the levels of the occluder cache.
 int rt_launch_bin_rays(const double* S, const double* E, int W, int rows, int lights, long stride,
-                       int which, int32_t* out, int* out_counts, hipStream_t st);
-constexpr int RT_SHADOW_SAMPLE = 4;
+                       int step_in, int step_out, int32_t* out, int* out_counts, hipStream_t st);
+// Pixel spacing of the occluder cache's levels, coarsest first; the last must be 1.  (A third,
+// coarser level -- 16, 4, 1 -- was measured: it saves 4 % of the pair tests and loses more than
+// that to its extra chain of small launches.)
+#ifndef RT_SHADOW_NEIGHBOURS
+#define RT_SHADOW_NEIGHBOURS 4      // samples per axis whose occluders a ray tries: the corners of its
+                                    // cell and the ring around them (2: 241 ms of shadow sweeps on the
+                                    // 1 M soup at 4K, 4: 227 ms, 6: 227 ms, 8: slower, the tries cost more)
+#endif
+constexpr int RT_SHADOW_LEVELS = 2;
+constexpr int RT_SHADOW_STEPS[RT_SHADOW_LEVELS] = {4, 1};
 // survivors of `sets` ray sets (stride entries apart in in/out; cnt of set s starts
 // (s / cnt_div) * stride rays in): set s takes its n from in_counts[s] when `in` is given, else
 // all n rays; writes out_counts[s]
@@ -272,7 +281,7 @@ int rt_launch_overflow_rays(const ExactScene& es, const double* S, const double*
 // is marked occluded in cnt[] on success.
 int rt_launch_try_cached(const ExactScene& es, const double* S, const double* E, const int32_t* lists,
                          const int* counts, int sets, int n_max, long stride, int W, int rows,
-                         int32_t* cnt, int32_t* occ_id, hipStream_t st);
+                         int step, bool record, int32_t* cnt, int32_t* occ_id, hipStream_t st);
 int rt_launch_single_ray(const ExactScene& es, const double* S_E_dev, double* out_dev,
                          hipStream_t st);
 

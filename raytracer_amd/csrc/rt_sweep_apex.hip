@@ -448,10 +448,10 @@ __global__ void __launch_bounds__(RT_WG, R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES)
 // out_counts[set].  Rays are visited in the order of the 64 x 16 pixel tiles, and every
 // workgroup writes its slice in that order, so the rays of a sweep workgroup stay neighbours on
 // the screen (they tend to retire together).  Unused slots (NaN origin) are left out, and
-// `which` selects all rays, the sample rays of the occluder cache, or the others.
+// step_in / step_out select the rays of one level of the occluder cache.
 __global__ void __launch_bounds__(RT_WG)
 k_bin_rays(const double* __restrict__ S, const double* __restrict__ E, int W, int rows, long stride,
-           int which, int32_t* __restrict__ out, int* __restrict__ out_counts)
+           int step_in, int step_out, int32_t* __restrict__ out, int* __restrict__ out_counts)
 {
     __shared__ int s_wave[RT_WG / 64][3];
     __shared__ int s_base[3];
@@ -471,10 +471,9 @@ k_bin_rays(const double* __restrict__ S, const double* __restrict__ E, int W, in
         const int w = (int)(e & 1023), tx = (int)(t % tiles_x), ty = (int)(t / tiles_x);
         const int px = tx * 64 + (w & 63), lr = ty * 16 + (w >> 6);
         if (px >= W || lr >= rows) return -1;
-        if (which) {        // 1: sample rays of the occluder cache only, 2: the others only
-            const bool sample = px % RT_SHADOW_SAMPLE == 0 && lr % RT_SHADOW_SAMPLE == 0;
-            if (sample != (which == 1)) return -1;
-        }
+        // one level of the occluder cache: on the step_in grid, not on the coarser step_out grid
+        if (px % step_in != 0 || lr % step_in != 0) return -1;
+        if (step_out > 0 && px % step_out == 0 && lr % step_out == 0) return -1;
         id = lr * W + px;
         const double* s = S + 3 * (long)id;
         const double* en = E + 3 * (long)id;
@@ -708,14 +707,18 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
 }
 
 int rt_launch_bin_rays(const double* S, const double* E, int W, int rows, int lights, long stride,
-                       int which, int32_t* out, int* out_counts, hipStream_t st)
+                       int step_in, int step_out, int32_t* out, int* out_counts, hipStream_t st)
 {
     if (W <= 0 || rows <= 0 || lights <= 0) return RT_OK;
+    if (step_in < 1 || step_out < 0) {
+        rt_set_error("bin_rays: bad sample steps");
+        return RT_E_ARG;
+    }
     const long total = (long)((W + 63) / 64) * ((rows + 15) / 16) * 1024;
     long wgs = (total + RT_WG - 1) / RT_WG;
     if (wgs > 2048) wgs = 2048;
     hipLaunchKernelGGL(k_bin_rays, dim3((unsigned)wgs, lights), dim3(RT_WG), 0, st, S, E, W, rows, stride,
-                       which, out, out_counts);
+                       step_in, step_out, out, out_counts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("bin_rays launch failed: %s", hipGetErrorString(e));

@@ -12,6 +12,7 @@ ap.add_argument("--workload", default="soup1m_4k")
 ap.add_argument("--ranks", type=int, nargs="+", default=[2, 4, 8])
 ap.add_argument("--detail", action="store_true")
 ap.add_argument("--bands", action="store_true")
+ap.add_argument("--block", type=int, default=16)
 a = ap.parse_args()
 kind, tris, W, H = bench.WORKLOADS[a.workload]
 mesh = bench.make_mesh(kind, tris)
@@ -45,6 +46,6 @@ for n in a.ranks:
             y0, y1 = kernel.band(H, n, r)
             ts.append(timed(kernel.rows_part(H, 1, 0, y1 - y0, y0, y1)))
         else:
-            ts.append(timed(kernel.rows_part(H, n, r)))
+            ts.append(timed(kernel.rows_part(H, n, r, a.block)))
     print(f"{n} parts: max {max(ts)*1e3:.1f} ms sum {sum(ts)*1e3:.1f} ms -> predicted speed-up {full/max(ts):.2f}x "
           f"(bands: {' '.join(f'{t*1e3:.0f}' for t in ts)})", flush=True)
