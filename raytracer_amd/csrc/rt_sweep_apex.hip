@@ -47,6 +47,9 @@
 #ifndef RT_RASTER_UNROLL
 #define RT_RASTER_UNROLL 4
 #endif
+#ifndef RT_RASTER_WAVES
+#define RT_RASTER_WAVES RT_MIN_WAVES    // waves per SIMD the pixel-grid sweep must fit
+#endif
 #ifndef RT_RASTER_CHAIN
 #define RT_RASTER_CHAIN 1   // the lane's pixels step along X by additions instead of one FMA each
 #endif
@@ -89,7 +92,7 @@ __device__ __forceinline__ void finish_raster(Book& bk, int32_t* __restrict__ li
 }
 
 template <int R>
-__global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep_raster(const SweepArgs A)
+__global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const SweepArgs A)
 {
     __shared__ float4 tile[2][RT_APEX_PLANES][RT_TILE];
 
