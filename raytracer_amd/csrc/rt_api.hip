@@ -173,7 +173,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
     DevBuf* bufs[] = {&sc->ox, &sc->oy, &sc->oz, &sc->ex, &sc->ey, &sc->ez, &sc->nx, &sc->ny, &sc->nz,
                       &sc->tu, &sc->tv, &sc->iA, &sc->iB, &sc->iC, &sc->iAn, &sc->iBn, &sc->iCn,
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts,
-                      &sc->scratch_max, &sc->mat_dev, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf,
+                      &sc->scratch_max, &sc->mat_dev, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
                       &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort};
     for (DevBuf* b : bufs) b->release();
@@ -583,8 +583,13 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     const size_t npix = (size_t)W * rows.rows;
     int rpl = 1, chunks = 1;
     rt_raster_shape(W, rows.rows, sc->num_tris_padded / RT_TILE, &rpl, &chunks);
-    RT_TRY(workspaces(sc, npix * (size_t)chunks));
+    const size_t slots = npix * (size_t)chunks;
+    RT_TRY(workspaces(sc, slots));
+    RT_TRY(sc->ws_besthi.reserve(sizeof(float) * slots));
     RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
+    // the sweep keeps its per-pixel state in memory: no candidates yet, no certain hit yet (+inf)
+    RT_HIP(hipMemsetAsync(sc->ws_cnt.p, 0, sizeof(int32_t) * slots, st));
+    RT_HIP(hipMemsetD32Async((hipDeviceptr_t)sc->ws_besthi.p, 0x7F800000, slots, st));
 
     // planes for rays from the eye; the constant z of the pixel-grid directions is folded in
     const double ez = (double)(W / 2) / tan_half;       // driver.c:133
@@ -598,6 +603,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     a.W = W; a.H = H; a.rows = rows;
     a.ez = ez;
     a.cnt = sc->ws_cnt.as<int32_t>(); a.list = sc->ws_list.as<int32_t>();
+    a.best_hi = sc->ws_besthi.as<float>();
     a.chunks = chunks; a.chunk_stride = (long)npix;
     a.tests = nullptr;
     a.tri_begin = 0; a.tri_end = sc->num_tris_padded;

@@ -58,7 +58,7 @@ constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
 // Sweeps of rays through a common point (rt_sweep_apex.hip): the eye for primary rays, a
 // light for its shadow rays.  4 float4 planes per triangle, packed per apex by k_pack_apex.
 #ifndef RT_RASTER_RPL
-#define RT_RASTER_RPL 8     // pixels per lane of the primary (pixel-grid) sweep
+#define RT_RASTER_RPL 16    // pixels per lane of the primary (pixel-grid) sweep
 #endif
 #ifndef RT_APEX_RPL
 #define RT_APEX_RPL 8       // rays per lane of the any-hit apex sweep
@@ -67,14 +67,19 @@ constexpr int RT_APEX_PLANES = 4;
 constexpr int RT_APEX_LIGHTS = 4;   // lights swept per any-hit launch (plane sets kept side by side)
 constexpr int RT_APEX_SETS = 3 * RT_APEX_LIGHTS;    // ray sets per launch: light x dominant axis
 // Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels): 2 FMA for the row terms,
-// 2 FMA for the first pixel, 2 additions for each further pixel, then per pixel one logic
-// instruction on the two sign bits, and one compare.  Apex sweep, per pair: two dot products
+// 2 FMA for the first pixel of every 8, 2 additions for each further pixel, then per pixel one
+// logic instruction on the two sign bits, and one compare.  Apex sweep, per pair: two dot products
 // with a unit dominant component (2 FMA each) + 1 FMA.
 struct RasterMix { int fma, add, logic, compare; };
-constexpr RasterMix rt_raster_mix(int rpl) { return RasterMix{4, 2 * (rpl - 1), rpl, 1}; }
-// fp32 flops per pair (FMA = 2) and VALU instructions per pair of that loop
-constexpr double rt_raster_flop_per_pair(int rpl) { return (2.0 * 4 + 2.0 * (rpl - 1)) / rpl; }
-constexpr double rt_raster_instr_per_pair(int rpl) { return (4.0 + 2.0 * (rpl - 1) + rpl + 1.0) / rpl; }
+constexpr RasterMix rt_raster_mix(int rpl)
+{
+    return RasterMix{2 + 2 * ((rpl + 7) / 8), 2 * (rpl - (rpl + 7) / 8), rpl, 1};
+}
+// fp32 flops per pair (FMA = 2) of that loop
+constexpr double rt_raster_flop_per_pair(int rpl)
+{
+    return (2.0 * rt_raster_mix(rpl).fma + rt_raster_mix(rpl).add) / rpl;
+}
 constexpr double RT_APEX_FLOP_PER_PAIR = 10.0;
 
 // per-ray candidate counter written by the sweep: low bits = candidates pushed, plus
@@ -119,7 +124,7 @@ struct rt_scene {
     DevBuf mat_dev;             // the 4x4 of the current transform
 
     // per-call workspaces (grow-only)
-    DevBuf ws_cnt, ws_list, ws_ovf, ws_counters;
+    DevBuf ws_cnt, ws_list, ws_ovf, ws_counters, ws_besthi;
     DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_act2, ws_live, ws_occid, ws_sort;
 };
 
@@ -217,6 +222,9 @@ struct SweepArgs {
     // separate workgroups; chunk c keeps its counts and lists chunk_stride rays further on
     int chunks;
     long chunk_stride;
+    // pixel-grid sweep only: per ray and chunk, the upper bound of the closest certain hit's t
+    // so far (+inf before the sweep); cnt[] must be zero before the sweep
+    float* best_hi;
     unsigned long long* tests;   // pairs evaluated, accumulated per workgroup (may be nullptr)
 };
 int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st);

@@ -50,9 +50,7 @@
 #ifndef RT_RASTER_WAVES
 #define RT_RASTER_WAVES RT_MIN_WAVES    // waves per SIMD the pixel-grid sweep must fit
 #endif
-#ifndef RT_RASTER_CHAIN
-#define RT_RASTER_CHAIN 1   // the lane's pixels step along X by additions instead of one FMA each
-#endif
+
 
 namespace {
 
@@ -66,17 +64,27 @@ __device__ __forceinline__ Tri2 load_tri2(const float4* p) { return {p[0], p[RT_
 // ------------------------------------------------------------------------------------------
 // primary rays on the pixel grid
 // ------------------------------------------------------------------------------------------
-// The rest of the inside test for one pixel that passed the sign tests of triangle `tri`.
-// Xs = the pixel's X / 8, un = its first sign-test value -(U + delta); p = the triangle's plane 0
-// in the LDS tile.
-__device__ __forceinline__ void finish_raster(Book& bk, int32_t* __restrict__ list_slot, int tri,
-                                              const Tri2& q, const float4* __restrict__ p,
-                                              float Xs, float Y, float un)
+// What the sweep keeps per pixel lives in memory, not in registers: cnt[] (candidates listed so
+// far) and best_hi[] (upper bound of the true t of the closest certain hit so far).  Only the
+// rare path touches them, a pixel belongs to one lane, and the hot loop is left with few enough
+// registers for eight waves per SIMD.
+__device__ __forceinline__ void push_mem(const SweepArgs& A, long slot, int tri)
+{
+    const int c = A.cnt[slot];
+    if (c < RT_LIST_K) A.list[slot * RT_LIST_K + c] = tri;
+    A.cnt[slot] = c + 1;
+}
+
+// The rest of the inside test for one pixel that passed the sign tests of triangle `tri`
+// (candidate() of rt_sweep_common.h with the bookkeeping in memory).  Xs = the pixel's X / 8,
+// un = its first sign-test value -(U + delta); p = the triangle's plane 0 in the LDS tile.
+__device__ __forceinline__ void finish_raster(const SweepArgs& A, long slot, int tri, const Tri2& q,
+                                              const float4* __restrict__ p, float Xs, float Y, float un)
 {
     const float4 Hh = p[2 * RT_TILE], N = p[3 * RT_TILE];
     const float margin = q.Q.w;
     if (margin == INF) {            // no fp32 verdict for this triangle (see k_pack_apex)
-        if (bk.best_hi != -INF) push(bk, list_slot, tri);
+        push_mem(A, slot, tri);
         return;
     }
     const float X = 8.0f * Xs;
@@ -86,9 +94,21 @@ __device__ __forceinline__ void finish_raster(Book& bk, int32_t* __restrict__ li
     const float a = U * d, b = V * d;
     const float w = __builtin_fmaf(d, d, -a) - b;
     const float m3 = __builtin_fminf(__builtin_fminf(a, b), w);
-    if (__builtin_fmaf(margin, __builtin_fabsf(d), m3) > 0.0f)
-        candidate<false>(bk, list_slot, tri, a, b, w, d, Hh.w, 0.0f, margin, N.w,
-                         U22 * __builtin_fabsf(Hh.w));
+    if (!(__builtin_fmaf(margin, __builtin_fabsf(d), m3) > 0.0f)) return;
+    const float ad = __builtin_fabsf(d), en = N.w;
+    const float den = ad - en;
+    if (!(den > 0.0f)) {            // determinant not resolved: the exact pass decides
+        push_mem(A, slot, tri);
+        return;
+    }
+    const float T = Hh.w, eT = U22 * __builtin_fabsf(T);
+    const float t = T / d;          // rays start at the apex: t0 = 0
+    const float terr = (eT + __builtin_fabsf(t) * en) / den * 1.000001f + U22 * __builtin_fabsf(t);
+    const float best_hi = A.best_hi[slot];
+    if (!(t >= -terr) || !(t - terr <= best_hi)) return;
+    push_mem(A, slot, tri);
+    // a certain hit (inside by the full margin, t resolved) bounds the closest hit's t from above
+    if (m3 >= margin * ad && t > terr && t + terr < best_hi) A.best_hi[slot] = t + terr;
 }
 
 template <int R>
@@ -112,16 +132,10 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
     // pixel r of the lane has X = px0 + 8 r - W/2 (driver.c:131); the planes carry 8 p.x, so
     // the sweep works with X / 8 = Xs0 + r (exact in fp32)
     const float Xs0 = (float)(px0 - A.W / 2) * 0.125f;
-    Book bk[R];
-    bool valid[R];
+    unsigned on_image = 0;          // bit r: pixel r of the lane exists
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int px = px0 + 8 * r;
-        valid[r] = (px < A.W) && (lr < A.rows.rows);
-        bk[r].best = INF;
-        bk[r].best_hi = valid[r] ? INF : -INF;
-        bk[r].cnt = valid[r] ? 0 : RT_CNT_RETIRED;
-    }
+    for (int r = 0; r < R; ++r)
+        on_image |= ((px0 + 8 * r < A.W) && (lr < A.rows.rows) ? 1u : 0u) << r;
 
     // this workgroup's share of the triangle range: chunk blockIdx.y of gridDim.y
     const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
@@ -157,25 +171,34 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
             int acc = __float_as_int(un) & __float_as_int(wn);
 #pragma unroll
             for (int r = 1; r < R; ++r) {
-#if RT_RASTER_CHAIN
-                un += cur.P.x;          // X / 8 grows by one from pixel to pixel
-                wn += cur.Q.x;
-#else
-                un = __builtin_fmaf(Xs0 + (float)r, cur.P.x, yu);
-                wn = __builtin_fmaf(Xs0 + (float)r, cur.Q.x, yw);
-#endif
+                if (r % 8 == 0) {       // a fresh start every 8 pixels bounds the rounding of the steps
+                    un = __builtin_fmaf(Xs0 + (float)r, cur.P.x, yu);
+                    wn = __builtin_fmaf(Xs0 + (float)r, cur.Q.x, yw);
+                } else {
+                    un += cur.P.x;      // X / 8 grows by one from pixel to pixel
+                    wn += cur.Q.x;
+                }
                 acc = (__float_as_int(un) & __float_as_int(wn)) | acc;      // v_and_or_b32
             }
             if (__builtin_expect(acc < 0, 0)) {
-                // which pixels: evaluated again, each from its own X (not kept in the hot loop)
+                // Which pixels: evaluated again, each from its own X (not kept in the hot loop).
+                // Hardly ever more than one per lane, so every lane finishes its first one and
+                // the wave repeats while some lane has another.
+                unsigned pass = 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const float Xs = Xs0 + (float)r;
                     const float u1 = __builtin_fmaf(Xs, cur.P.x, yu);
                     const float w1 = __builtin_fmaf(Xs, cur.Q.x, yw);
-                    if ((__float_as_int(u1) & __float_as_int(w1)) < 0)
-                        finish_raster(bk[r], A.list + (slot0 + 8 * r) * RT_LIST_K, tri0 + j, cur,
-                                      base + j, Xs, Y, u1);
+                    pass |= ((unsigned)(__float_as_int(u1) & __float_as_int(w1)) >> 31) << r;
+                }
+                pass &= on_image;
+                while (pass) {
+                    const int rs = __builtin_ctz(pass);
+                    pass &= pass - 1;
+                    const float Xs = Xs0 + (float)rs;
+                    finish_raster(A, slot0 + 8 * rs, tri0 + j, cur, base + j, Xs, Y,
+                                  __builtin_fmaf(Xs, cur.P.x, yu));
                 }
             }
         }
@@ -184,9 +207,6 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
         __syncthreads();
     }
 
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (valid[r]) A.cnt[slot0 + 8 * r] = bk[r].cnt;
     if (A.tests && tid == 0)
         atomicAdd(A.tests, tiles_done * (unsigned long long)RT_TILE * (RT_WG * R));
 }
@@ -601,6 +621,9 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     if (max_chunks > cap) max_chunks = cap;
     int r = RT_RASTER_RPL;
     while (r > 1 && 16 * r > W + 8 * r) r /= 2;         // no lane set mostly off the image
+    // 16 pixels per lane save 3 % over 8 (measured), less than a half-empty last tile column costs
+    auto padded = [&](int rr) { return (long)((W + 16 * rr - 1) / (16 * rr)) * (16 * rr); };
+    if (r == 16 && padded(16) * 100 > padded(8) * 102) r = 8;
     for (;;) {
         const long wgs = (long)((W + 16 * r - 1) / (16 * r)) * tiles_y;
         if (wgs * max_chunks >= slots || r == 1) {
@@ -621,6 +644,10 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
     if (rc) return rc;
     if (a.W <= 0 || a.H <= 0 || a.rows.rows <= 0 || a.rows.block <= 0 || a.rows.parts <= 0) {
         rt_set_error("raster sweep: empty band");
+        return RT_E_ARG;
+    }
+    if (!a.best_hi) {
+        rt_set_error("raster sweep: null buffer");
         return RT_E_ARG;
     }
     int r = 1, chunks = 1;
