@@ -610,7 +610,8 @@ static int device_cus()
 // 8 chunks instead of 1 take 6 % off a 3840x2160 sweep and 33 % off a 3840x270 one, at the
 // price of three times as many candidates for the exact pass (less pruning across chunks).
 // A chunk keeps at least 8 tiles; a mesh too small to fill the machine that way gives up
-// pixels per lane instead.
+// pixels per lane instead.  RT_AMD_RASTER_FORCE="<pixels per lane>,<chunks>" overrides the
+// choice (read at every call: tests use it to run every kernel shape on small inputs).
 void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks)
 {
     const long slots = 5L * device_cus();           // resident workgroups
@@ -619,6 +620,15 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     if (max_chunks < 1) max_chunks = 1;
     static const int cap = getenv("RT_AMD_RASTER_MAX_CHUNKS") ? atoi(getenv("RT_AMD_RASTER_MAX_CHUNKS")) : RT_RASTER_MAX_CHUNKS;
     if (max_chunks > cap) max_chunks = cap;
+    if (const char* force = getenv("RT_AMD_RASTER_FORCE")) {
+        int fr = 0, fc = 0;
+        if (sscanf(force, "%d,%d", &fr, &fc) == 2 && fc >= 1 && fc <= (tiles < 1 ? 1 : tiles) &&
+            (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == RT_RASTER_RPL)) {
+            *pixels_per_lane = fr;
+            *chunks = fc;
+            return;
+        }
+    }
     int r = RT_RASTER_RPL;
     while (r > 1 && 16 * r > W + 8 * r) r /= 2;         // no lane set mostly off the image
     // 16 pixels per lane save 3 % over 8 (measured), less than a half-empty last tile column costs
@@ -718,12 +728,23 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
         return RT_E_ARG;
     }
     if (a.n_rays <= 0) return RT_OK;
-    const int max_chunks = apex_max_chunks((a.tri_end - a.tri_begin) / RT_TILE);
-    const int r = apex_rays_per_lane(a.total_rays > 0 ? a.total_rays : (long)a.n_rays * a.lights, max_chunks);
+    const int tiles = (a.tri_end - a.tri_begin) / RT_TILE;
+    const int max_chunks = apex_max_chunks(tiles);
+    int r = apex_rays_per_lane(a.total_rays > 0 ? a.total_rays : (long)a.n_rays * a.lights, max_chunks);
+    int forced_chunks = 0;
+    // RT_AMD_APEX_FORCE="<rays per lane>,<chunks>": tests run every kernel shape on small inputs
+    if (const char* force = getenv("RT_AMD_APEX_FORCE")) {
+        int fr = 0, fc = 0;
+        if (sscanf(force, "%d,%d", &fr, &fc) == 2 && fc >= 1 &&
+            (fr == 1 || fr == 2 || fr == 4 || fr == RT_APEX_RPL)) {
+            r = fr;
+            forced_chunks = fc > tiles ? (tiles < 1 ? 1 : tiles) : fc;
+        }
+    }
     const int per_wg = RT_WG * r;
     const unsigned wgs = (unsigned)((a.n_rays + per_wg - 1) / per_wg);
     const long all_wgs = a.total_rays > 0 ? (a.total_rays + per_wg - 1) / per_wg + a.lights : (long)wgs * a.lights;
-    const dim3 grid(wgs, a.lights, apex_chunks(all_wgs, max_chunks));
+    const dim3 grid(wgs, a.lights, forced_chunks ? forced_chunks : apex_chunks(all_wgs, max_chunks));
     switch (r) {
     case 1: return launch(k_sweep_apex<1>, a, grid, st, "apex sweep");
     case 2: return launch(k_sweep_apex<2>, a, grid, st, "apex sweep");

@@ -301,3 +301,39 @@ def test_triangles_whose_plane_contains_the_eye(through_eye):
     assert np.array_equal(out["tuv"][m], ref["tuv"][m])
     assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
     sc.close()
+
+
+@pytest.mark.parametrize("shape", ["16,1", "16,3", "8,2", "4,1", "2,5", "1,1"])
+@pytest.mark.parametrize("W,H", [(500, 20), (37, 19)])
+def test_every_shape_of_the_pixel_grid_sweep(shape, W, H, monkeypatch):
+    """The launcher picks pixels per lane and triangle chunks from the image and mesh size, so
+    small inputs never reach the shapes large frames run with: force each one (lanes whose
+    pixels are partly or wholly off the image, chunks of uneven length) and compare with the
+    oracle."""
+    monkeypatch.setenv("RT_AMD_RASTER_FORCE", shape)
+    mesh = scenes.triangle_soup(700, seed=5)
+    fr = kernel.driver_frame(4)
+    ref, _ = _ref(mesh, fr, W, H)
+    sc, out = _gpu(mesh, fr, W, H)
+    assert (ref["hit"] >= 0).mean() > 0.05
+    assert np.array_equal(out["hit"], ref["hit"])
+    m = ref["hit"] >= 0
+    assert np.array_equal(out["tuv"][m], ref["tuv"][m])
+    assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    sc.close()
+
+
+@pytest.mark.parametrize("shape", ["8,1", "8,4", "4,3", "2,2", "1,7"])
+def test_every_shape_of_the_any_hit_sweep(shape, monkeypatch):
+    """Same for the shadow rays' sweep: rays per lane and triangle chunks that share a ray's
+    candidate list through atomics (more chunks than a few-tile range can feed included)."""
+    monkeypatch.setenv("RT_AMD_APEX_FORCE", shape)
+    mesh = scenes.triangle_soup(900, seed=9)
+    fr = kernel.driver_frame(6)
+    W, H = 150, 70
+    ref, _ = _ref(mesh, fr, W, H)
+    sc, out = _gpu(mesh, fr, W, H)
+    assert ref["shadow_rays"] > 1000
+    assert np.array_equal(out["hit"], ref["hit"])
+    assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    sc.close()
