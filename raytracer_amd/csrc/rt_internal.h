@@ -60,6 +60,7 @@ constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
 #ifndef RT_RASTER_RPL
 #define RT_RASTER_RPL 16    // pixels per lane of the primary (pixel-grid) sweep
 #endif
+#define RT_RASTER_COLS 4     // pixel columns a lane's pixels are apart (a wave is COLS R x 64/COLS pixels)
 #ifndef RT_APEX_RPL
 #define RT_APEX_RPL 8       // rays per lane of the any-hit apex sweep
 #endif

@@ -76,7 +76,7 @@ __device__ __forceinline__ void push_mem(const SweepArgs& A, long slot, int tri)
 }
 
 // The rest of the inside test for one pixel that passed the sign tests of triangle `tri`
-// (candidate() of rt_sweep_common.h with the bookkeeping in memory).  Xs = the pixel's X / 8,
+// (candidate() of rt_sweep_common.h with the bookkeeping in memory).  Xs = the pixel's X / RT_RASTER_COLS,
 // un = its first sign-test value -(U + delta); p = the triangle's plane 0 in the LDS tile.
 __device__ __forceinline__ void finish_raster(const SweepArgs& A, long slot, int tri, const Tri2& q,
                                               const float4* __restrict__ p, float Xs, float Y, float un)
@@ -87,7 +87,7 @@ __device__ __forceinline__ void finish_raster(const SweepArgs& A, long slot, int
         push_mem(A, slot, tri);
         return;
     }
-    const float X = 8.0f * Xs;
+    const float X = (float)RT_RASTER_COLS * Xs;
     const float U = -un - q.P.w;
     const float V = __builtin_fmaf(X, Hh.x, __builtin_fmaf(Y, Hh.y, Hh.z));
     const float d = __builtin_fmaf(X, N.x, __builtin_fmaf(Y, N.y, N.z));
@@ -120,22 +120,26 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    // workgroup = (16 R) x 16 pixels; wave = (8 R) x 8; lane = one row, R pixels 8 apart
+    // workgroup = (16 R) x 16 pixels, its four waves side by side; wave = (COLS R) x (64 / COLS)
+    // pixels; lane = one row, R pixels COLS apart.  (The squarer a wave's pixels, the fewer
+    // triangles have one of them in their slab: the rare path is paid per wave.)
+    constexpr int COLS = RT_RASTER_COLS;
+    static_assert(4 * COLS == 16 && 64 / COLS == RT_TILE_H, "workgroup tile is (16 R) x RT_TILE_H pixels");
     const int tiles_x = (A.W + 16 * R - 1) / (16 * R);
     const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int px0 = txi * (16 * R) + (wave & 1) * (8 * R) + (lane & 7);
-    const int lr = tyi * 16 + (wave >> 1) * 8 + (lane >> 3);       // local row of the call's row set
+    const int px0 = txi * (16 * R) + wave * (COLS * R) + (lane % COLS);
+    const int lr = tyi * RT_TILE_H + lane / COLS;                  // local row of the call's row set
     const float Y = (float)(A.rows.image_row(lr) - A.H / 2);        // driver.c:132
     // ray number: local pixel, in the segment of this workgroup's triangle chunk
     const long slot0 = (long)blockIdx.y * A.chunk_stride + (long)lr * A.W + px0;
 
-    // pixel r of the lane has X = px0 + 8 r - W/2 (driver.c:131); the planes carry 8 p.x, so
-    // the sweep works with X / 8 = Xs0 + r (exact in fp32)
-    const float Xs0 = (float)(px0 - A.W / 2) * 0.125f;
+    // pixel r of the lane has X = px0 + COLS r - W/2 (driver.c:131); the planes carry COLS p.x,
+    // so the sweep works with X / COLS = Xs0 + r (exact in fp32)
+    const float Xs0 = (float)(px0 - A.W / 2) * (1.0f / COLS);
     unsigned on_image = 0;          // bit r: pixel r of the lane exists
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        on_image |= ((px0 + 8 * r < A.W) && (lr < A.rows.rows) ? 1u : 0u) << r;
+        on_image |= ((px0 + COLS * r < A.W) && (lr < A.rows.rows) ? 1u : 0u) << r;
 
     // this workgroup's share of the triangle range: chunk blockIdx.y of gridDim.y
     const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
@@ -175,7 +179,7 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
                     un = __builtin_fmaf(Xs0 + (float)r, cur.P.x, yu);
                     wn = __builtin_fmaf(Xs0 + (float)r, cur.Q.x, yw);
                 } else {
-                    un += cur.P.x;      // X / 8 grows by one from pixel to pixel
+                    un += cur.P.x;      // X / COLS grows by one from pixel to pixel
                     wn += cur.Q.x;
                 }
                 acc = (__float_as_int(un) & __float_as_int(wn)) | acc;      // v_and_or_b32
@@ -197,7 +201,7 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
                     const int rs = __builtin_ctz(pass);
                     pass &= pass - 1;
                     const float Xs = Xs0 + (float)rs;
-                    finish_raster(A, slot0 + 8 * rs, tri0 + j, cur, base + j, Xs, Y,
+                    finish_raster(A, slot0 + COLS * rs, tri0 + j, cur, base + j, Xs, Y,
                                   __builtin_fmaf(Xs, cur.P.x, yu));
                 }
             }

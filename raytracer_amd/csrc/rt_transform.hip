@@ -199,10 +199,10 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
         // t = k / det > 0, so det has the sign of k, and so have U and W' (0 <= u <= 1).  With
         // every vector multiplied by s = sign(k) the u slab is U >= 0 and W' >= 0, which the
         // sweep reads off two sign bits:
-        //     plane 0 = (-8 s p.x, -s p.y, -s p.z zs - delta, delta)    D.plane0 = -(U + delta)
-        //     plane 1 = (-8 s q.x, -s q.y, -s q.z zs - delta, m)        D.plane1 = -(W' + delta)
+        //     plane 0 = (-c s p.x, -s p.y, -s p.z zs - delta, delta)    D.plane0 = -(U + delta)
+        //     plane 1 = (-c s q.x, -s q.y, -s q.z zs - delta, m)        D.plane1 = -(W' + delta)
         //     plane 2 = s (h, k)     plane 3 = (s nn, en)
-        // for D = (X / 8, Y, 1).  delta (16 * 2^-24 dmax rho l) covers the rounding of the stored
+        // for D = (X / c, Y, 1), c = RT_RASTER_COLS (the pixels of a lane are c columns apart).  delta (16 * 2^-24 dmax rho l) covers the rounding of the stored
         // constants, of the two FMAs and of the seven additions that step along a lane's pixels.
         // When k is too small for its sign to be trusted (P within rounding of the triangle's
         // plane, which includes the nearly degenerate triangles) no fp32 verdict is possible and
@@ -217,8 +217,9 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
         }
         const double sg = k < 0.0 ? -1.0 : 1.0;
         const float df = (float)delta * 1.0000002f;
-        *p[0] = make_float4((float)(-8.0 * sg * ux), (float)(-sg * uy), (float)(-sg * zs * uz - delta), df);
-        *p[1] = make_float4((float)(-8.0 * sg * qx_), (float)(-sg * qy_), (float)(-sg * zs * qz_ - delta), (float)m);
+        const double xs = (double)RT_RASTER_COLS;
+        *p[0] = make_float4((float)(-xs * sg * ux), (float)(-sg * uy), (float)(-sg * zs * uz - delta), df);
+        *p[1] = make_float4((float)(-xs * sg * qx_), (float)(-sg * qy_), (float)(-sg * zs * qz_ - delta), (float)m);
         *p[2] = make_float4((float)(sg * hx), (float)(sg * hy), (float)(sg * zs * hz), (float)(sg * k));
         *p[3] = make_float4((float)(sg * nx), (float)(sg * ny), (float)(sg * zs * nz), (float)en * 1.0000002f);
         return;
