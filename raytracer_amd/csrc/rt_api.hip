@@ -175,7 +175,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts,
                       &sc->scratch_max, &sc->mat_dev, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
-                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort};
+                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort, &sc->tri_order};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : sc->tex_data) b.release();
     delete sc;
@@ -595,7 +595,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     const double ez = (double)(W / 2) / tan_half;       // driver.c:133
     const double eye[3] = {0, 0, 0};                    // driver.c:121-123
     const double hw = 0.5 * W + 1, hh = 0.5 * H + 1;
-    RT_TRY(rt_launch_pack_apex(sc, eye, ez, sqrt(hw * hw + hh * hh + ez * ez), 0, true, st));
+    RT_TRY(rt_launch_pack_apex(sc, eye, ez, sqrt(hw * hw + hh * hh + ez * ez), 0, true, nullptr, st));
 
     SweepArgs a{};
     a.planes = sc->planes_apex.as<float4>(); a.plane_stride = sc->num_tris_padded;
@@ -809,9 +809,21 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows,
         RT_TRY(sc->planes_apex.reserve(sizeof(float4) * (size_t)sc->num_tris_padded * RT_APEX_PLANES * lights));
         RT_TRY(anyhit_buffers(sc, npix * 3 * (size_t)lights));
         // |D'| <= sqrt(3) for a direction scaled to a unit dominant component
-        for (int k = 0; k < lights; ++k)
-            RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l0 + k], 1.0, 1.75, k, false, st));
+        // every light's planes in the order of the solid angle the triangles subtend at it
+        // (rt_sort.hip): occluded rays meet an occluder sooner
+        static const bool sort_tris = !(getenv("RT_AMD_SORT_TRIS") && atoi(getenv("RT_AMD_SORT_TRIS")) == 0);
+        int32_t* order = nullptr;
+        if (sort_tris) {
+            RT_TRY(sc->tri_order.reserve(sizeof(int32_t) * (size_t)sc->num_tris_padded * lights));
+            order = sc->tri_order.as<int32_t>();
+        }
+        for (int k = 0; k < lights; ++k) {
+            int32_t* ord = order ? order + (size_t)k * sc->num_tris_padded : nullptr;
+            if (ord) RT_TRY(rt_launch_sort_triangles(sc, f->light_in_eye_space[l0 + k], ord, st));
+            RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l0 + k], 1.0, 1.75, k, false, ord, st));
+        }
         SweepArgs a{};
+        a.tri_order = order;
         a.planes = sc->planes_apex.as<float4>(); a.plane_stride = sc->num_tris_padded;
         a.light_plane_stride = (long)RT_APEX_PLANES * sc->num_tris_padded;
         a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;

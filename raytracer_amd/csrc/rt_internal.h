@@ -119,7 +119,7 @@ struct rt_scene {
     // (contents per formulation: k_pack in rt_transform.hip)
     DevBuf planes;
     // same for the apex sweeps: RT_APEX_PLANES planes, repacked for the eye and for each light
-    DevBuf planes_apex;
+    DevBuf planes_apex, tri_order;
     DevBuf tri_verts;           // 9 doubles per triangle, eye space (see ExactScene::tv)
     DevBuf scratch_max;         // 1 float: max |coordinate| of the eye-space vertices
     DevBuf mat_dev;             // the 4x4 of the current transform
@@ -170,7 +170,8 @@ int rt_launch_pack(rt_scene* sc, hipStream_t st);
 // apex planes for rays through `apex`; zs is folded into the z components (the constant z of
 // pixel-grid directions, 1 otherwise); dmax bounds |D| of every ray of the sweep
 int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, int set,
-                        bool sign_layout, hipStream_t st);      // into plane set `set` of sc->planes_apex
+                        bool sign_layout, const int32_t* order, hipStream_t st);
+// into plane set `set` of sc->planes_apex; order (or nullptr): entry k holds triangle order[k]
 
 // The pixel rows one call works on: one block of `block` rows out of every `parts` (rt_rows in
 // the public header); parts = 1 is the contiguous band [y0, y0 + rows).  Outputs are indexed by
@@ -219,6 +220,8 @@ struct SweepArgs {
     const int* live_counts;
     long total_rays;
     int32_t* occ_id;        // per ray (laid out like cnt): the triangle of its certain hit, or nullptr
+    // entry k of light l's planes holds triangle tri_order[l * num_tris_padded + k] (nullptr: k)
+    const int32_t* tri_order;
     // pixel-grid sweep only: the triangle range is cut into `chunks` equal parts that run as
     // separate workgroups; chunk c keeps its counts and lists chunk_stride rays further on
     int chunks;
@@ -254,6 +257,7 @@ constexpr int RT_SHADOW_STEPS[RT_SHADOW_LEVELS] = {4, 1};
 // survivors of `sets` ray sets (stride entries apart in in/out; cnt of set s starts
 // (s / cnt_div) * stride rays in): set s takes its n from in_counts[s] when `in` is given, else
 // all n rays; writes out_counts[s]
+int rt_launch_sort_triangles(rt_scene* sc, const double apex[3], int32_t* order, hipStream_t st);
 int rt_launch_sort_rays(rt_scene* sc, const double* S, const double* E, const int32_t* ids_in,
                         int32_t* ids_out, const int* counts, const int* counts_dev, int sets,
                         long stride, hipStream_t st);

@@ -53,7 +53,64 @@ k_ray_keys(const double* __restrict__ S, const double* __restrict__ E, const int
     }
 }
 
+// Solid angle a triangle subtends at the apex (Van Oosterom and Strackee), as a sort key: the
+// larger, the more of the rays through the apex the triangle can stop.
+__global__ void __launch_bounds__(RT_WG)
+k_tri_keys(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+           const int* __restrict__ iA, const int* __restrict__ iB, const int* __restrict__ iC,
+           int num_tris, int num_tris_padded, double px, double py, double pz,
+           unsigned* __restrict__ keys, int32_t* __restrict__ ids)
+{
+    const int i = blockIdx.x * RT_WG + threadIdx.x;
+    if (i >= num_tris_padded) return;
+    float omega = -1.0f;                        // padding sorts last
+    if (i < num_tris) {
+        const int a = iA[i], b = iB[i], c = iC[i];
+        const double ax = x[a] - px, ay = y[a] - py, az = z[a] - pz;
+        const double bx = x[b] - px, by = y[b] - py, bz = z[b] - pz;
+        const double cx = x[c] - px, cy = y[c] - py, cz = z[c] - pz;
+        const double ra = sqrt(ax * ax + ay * ay + az * az), rb = sqrt(bx * bx + by * by + bz * bz),
+                     rc = sqrt(cx * cx + cy * cy + cz * cz);
+        const double num = fabs(ax * (by * cz - bz * cy) + ay * (bz * cx - bx * cz) + az * (bx * cy - by * cx));
+        const double den = ra * rb * rc + (ax * bx + ay * by + az * bz) * rc +
+                           (ax * cx + ay * cy + az * cz) * rb + (bx * cx + by * cy + bz * cz) * ra;
+        const double w = 2.0 * atan2(num, den);
+        omega = (w == w) ? (float)w : 0.0f;
+    }
+    // descending order of omega through an ascending sort: non-negative floats order like their bits
+    keys[i] = omega < 0.0f ? 0xFFFFFFFFu : 0x7FFFFFFFu - __float_as_uint(omega);
+    ids[i] = i < num_tris ? i : -1;
+}
+
 }  // namespace
+
+// Order in which the any-hit sweep of the rays through `apex` visits the triangles: by the solid
+// angle they subtend there, largest first, so that occluded rays meet an occluder early.  An
+// any-hit query does not depend on the order in which triangles are tried.  order[k] = triangle
+// at position k, -1 for the padding at the end.
+int rt_launch_sort_triangles(rt_scene* sc, const double apex[3], int32_t* order, hipStream_t st)
+{
+    const unsigned np = (unsigned)sc->num_tris_padded;
+    if (np == 0) return RT_OK;
+    size_t temp_bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, temp_bytes, (unsigned*)nullptr, (unsigned*)nullptr,
+                                  (int32_t*)nullptr, (int32_t*)nullptr, np, 0u, 32u, st) != hipSuccess) {
+        rt_set_error("triangle sort: size query failed");
+        return RT_E_HIP;
+    }
+    const size_t arr = ((size_t)np * 4 + 255) & ~(size_t)255;
+    if (int rc = sc->ws_sort.reserve(3 * arr + temp_bytes)) return rc;
+    unsigned* keys_in = sc->ws_sort.as<unsigned>();
+    unsigned* keys_out = reinterpret_cast<unsigned*>(sc->ws_sort.as<char>() + arr);
+    int32_t* ids_in = reinterpret_cast<int32_t*>(sc->ws_sort.as<char>() + 2 * arr);
+    void* temp = sc->ws_sort.as<char>() + 3 * arr;
+    hipLaunchKernelGGL(k_tri_keys, dim3((np + RT_WG - 1) / RT_WG), dim3(RT_WG), 0, st, sc->ex.as<double>(),
+                       sc->ey.as<double>(), sc->ez.as<double>(), sc->iA.as<int>(), sc->iB.as<int>(),
+                       sc->iC.as<int>(), sc->num_tris, (int)np, apex[0], apex[1], apex[2], keys_in, ids_in);
+    RT_HIP(hipGetLastError());
+    RT_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, ids_in, order, np, 0u, 32u, st));
+    return RT_OK;
+}
 
 // Sorts the ray numbers of every set (ids_in[s * stride ...], counts[s] of them; counts_dev the
 // same numbers on the device) by direction into ids_out.  Sets smaller than min_rays are copied.

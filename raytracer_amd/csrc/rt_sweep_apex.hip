@@ -306,13 +306,14 @@ __device__ __forceinline__ bool finish_apex(const SweepArgs& A, float u, float v
         // unit direction, from S: t = len + sig * tau (the reference's t times len; only its
         // sign matters for an any-hit query, triangle_intersection.cu:169).
         const float T = sig * Hh.w;
+        // `tri` is the entry of the plane arrays; lists and the occluder cache hold triangle numbers
         return candidate_shared(A.cnt + sl, A.list + (long)sl * RT_LIST_K,
-                                A.occ_id ? A.occ_id + sl : nullptr, tri, a, b, w, d, T, len, margin,
-                                N.w, U22 * __builtin_fabsf(T));
+                                A.occ_id ? A.occ_id + sl : nullptr, A.tri_order ? A.tri_order[tri] : tri,
+                                a, b, w, d, T, len, margin, N.w, U22 * __builtin_fabsf(T));
     }
     const int sl = A.active[jr];
     const int at = atomicAdd(A.cnt + sl, 1) & RT_CNT_MASK;
-    if (at < RT_LIST_K) A.list[(long)sl * RT_LIST_K + at] = tri;
+    if (at < RT_LIST_K) A.list[(long)sl * RT_LIST_K + at] = A.tri_order ? A.tri_order[tri] : tri;
     return false;
 }
 
@@ -421,6 +422,7 @@ __global__ void __launch_bounds__(RT_WG, R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES)
     A.cnt += light * A.light_ray_stride;
     A.list += light * A.light_ray_stride * RT_LIST_K;
     if (A.occ_id) A.occ_id += light * A.light_ray_stride;
+    if (A.tri_order) A.tri_order += light * A.num_tris_padded;
     A.active += set * A.light_ray_stride;
     A.n_rays = A.live_counts[set];
     if ((long)blockIdx.x * (RT_WG * R) >= A.n_rays) return;     // the grid is sized for the largest set

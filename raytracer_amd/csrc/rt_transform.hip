@@ -117,18 +117,19 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
             const int* __restrict__ iA, const int* __restrict__ iB, const int* __restrict__ iC,
             int num_tris, int num_tris_padded, const unsigned* __restrict__ max_bits,
             double px, double py, double pz, double zs, double dmax, int sign_layout,
-            float4* __restrict__ planes)
+            const int32_t* __restrict__ order, float4* __restrict__ planes)
 {
-    const int i = blockIdx.x * RT_WG + threadIdx.x;
+    const int i = blockIdx.x * RT_WG + threadIdx.x;      // entry of the plane arrays
     if (i >= num_tris_padded) return;
+    const int src = order ? order[i] : (i < num_tris ? i : -1);     // the triangle it holds
     float4* p[RT_APEX_PLANES];
 #pragma unroll
     for (int k = 0; k < RT_APEX_PLANES; ++k) p[k] = planes + (long)k * num_tris_padded + i;
     const float4 null_entry = make_float4(0, 0, 0, -1.0f);
-    bool null_tri = i >= num_tris;
+    bool null_tri = src < 0 || src >= num_tris;
     double a0x = 0, a0y = 0, a0z = 0, a1x = 0, a1y = 0, a1z = 0, a2x = 0, a2y = 0, a2z = 0;
     if (!null_tri) {
-        const int a = iA[i], b = iB[i], c = iC[i];
+        const int a = iA[src], b = iB[src], c = iC[src];
         a0x = x[a] - px; a0y = y[a] - py; a0z = z[a] - pz;
         a1x = x[b] - px; a1y = y[b] - py; a1z = z[b] - pz;
         a2x = x[c] - px; a2y = y[c] - py; a2z = z[c] - pz;
@@ -233,7 +234,7 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
 }  // namespace
 
 int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, int set,
-                        bool sign_layout, hipStream_t st)
+                        bool sign_layout, const int32_t* order, hipStream_t st)
 {
     const int np = sc->num_tris_padded;
     if (set < 0 || set >= RT_APEX_SETS) {
@@ -244,7 +245,7 @@ int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dm
                        sc->ex.as<double>(), sc->ey.as<double>(), sc->ez.as<double>(),
                        sc->iA.as<int>(), sc->iB.as<int>(), sc->iC.as<int>(), sc->num_tris, np,
                        sc->scratch_max.as<unsigned>(), apex[0], apex[1], apex[2], zs, dmax,
-                       sign_layout ? 1 : 0, sc->planes_apex.as<float4>() + (size_t)set * RT_APEX_PLANES * np);
+                       sign_layout ? 1 : 0, order, sc->planes_apex.as<float4>() + (size_t)set * RT_APEX_PLANES * np);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("apex pack launch failed: %s", hipGetErrorString(e));
