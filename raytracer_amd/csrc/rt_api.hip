@@ -665,7 +665,7 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
     const int cnt_div = binned ? 3 : 1;
     int32_t* act[2] = {sc->ws_act0.as<int32_t>(), sc->ws_act1.as<int32_t>()};
     int* live_dev[2] = {sc->ws_live.as<int>(), sc->ws_live.as<int>() + RT_APEX_SETS};
-    static const double growth = getenv("RT_AMD_RANGE_GROWTH") ? atof(getenv("RT_AMD_RANGE_GROWTH")) : 1.5;
+    static const double growth = getenv("RT_AMD_RANGE_GROWTH") ? atof(getenv("RT_AMD_RANGE_GROWTH")) : 2.0;
     static const int first_div = getenv("RT_AMD_RANGE_FIRST") ? atoi(getenv("RT_AMD_RANGE_FIRST")) : 64;
     int first = np / first_div;
     first = ((first + RT_TILE - 1) / RT_TILE) * RT_TILE;
