@@ -8,28 +8,30 @@
 // vanishes when the triangle is expressed relative to the shared point P, and the three
 // determinants become plain dot products of the ray direction with per-triangle vectors
 // (k_pack_apex, rt_transform.hip):   U = D.p   W' = det - U = D.q   V = D.h   det = D.nn.
-// A pair lies in the u slab (0 <= u <= 1) exactly when U and W' have the sign of det, and
-// since U + W' = det that is when U * W' >= 0.  The hot loop therefore evaluates, per pair,
+// A pair lies in the u slab (0 <= u <= 1) exactly when U and W' have the sign of det.  That is
+// the first test of a pair in both kernels; the rare path behind it finishes the inside test
+// (V, det, the v and u+v edges, the ray parameter) and appends survivors to the ray's candidate
+// list; the fp64 pass of rt_exact.hip then decides with the reference's exact arithmetic.
 //
-//     s = fma(U, W', c)        and enters the rare path when s >= 0,
-//
-// where c is the per-triangle rounding allowance that makes the fp32 test a conservative
-// filter (derivation at k_pack_apex).  The rare path finishes the inside test (V, det, the
-// v and u+v edges, the ray parameter) and appends survivors to the ray's candidate list; the
-// fp64 pass of rt_exact.hip then decides with the reference's exact arithmetic.
-//
-//   k_sweep_apex    any-hit, for the shadow rays of up to four lights.  Directions are scaled to
+//   k_sweep_apex    any-hit, for the shadow rays of up to four lights.  Since U + W' = det, the
+//                   slab is U * W' >= 0: per pair  s = fma(U, W', c)  with c the per-triangle
+//                   rounding allowance that makes the fp32 test a conservative filter
+//                   (derivation at k_pack_apex), rare path when s >= 0.  Directions are scaled to
 //                   a unit dominant component (rays binned by that axis, k_bin_rays), so a dot
 //                   product is two FMAs: 5 FMA + the sign test = 5.6 VALU instructions per pair.
-//                   Triangle ranges with survivor compaction in between, triangle chunks that
-//                   share a ray's state through atomics, an occluder cache in front (host side:
+//                   Triangles in the order of their solid angle at the light, triangle ranges
+//                   with survivor compaction in between, triangle chunks that share a ray's
+//                   state through atomics, an occluder cache in front (host side:
 //                   trace_shadow_rays in rt_api.hip).
 //   k_sweep_raster  closest hit for the pixel grid.  D = (X, Y, ez) with integer X, Y and a
-//                   constant ez that k_pack_apex folds into the z components, and each lane
-//                   owns RT_RASTER_RPL pixels of one row, so the row part Y*p.y + ez*p.z is
-//                   formed once per lane and triangle and each pixel adds one FMA:
-//                   (2 + 3*RPL) FMA + the sign tests per RPL pairs, about 4 VALU instructions
-//                   per pair.  Every (pixel, triangle) pair is still tested individually.
+//                   constant ez that k_pack_apex folds into the z components.  Primary rays
+//                   leave P, which fixes the sign of det for a hit, so k_pack_apex orients every
+//                   triangle and the slab is U >= 0 and W' >= 0: two sign bits.  Each lane owns
+//                   RT_RASTER_RPL pixels of one row, RT_RASTER_COLS columns apart; the row part
+//                   Y*p.y + ez*p.z is formed once per lane and triangle, the first pixel costs
+//                   two FMAs and every further one two additions, and one logic instruction per
+//                   pixel combines the sign bits: 51 VALU instructions per 16 pairs.  Every
+//                   (pixel, triangle) pair is still tested individually.
 //
 // Tiles of RT_TILE triangles (4 planes) are double-buffered in LDS by LDS-DMA loads and read
 // at wave-uniform addresses (broadcast, no bank conflicts).
@@ -50,7 +52,6 @@
 #ifndef RT_RASTER_WAVES
 #define RT_RASTER_WAVES RT_MIN_WAVES    // waves per SIMD the pixel-grid sweep must fit
 #endif
-
 
 namespace {
 
