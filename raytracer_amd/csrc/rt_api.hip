@@ -682,7 +682,10 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
     };
     if (binned) RT_TRY(fetch_counts(live_dev[0]));
     // a sweep of a few milliseconds is not worth the compaction round trips
-    if ((double)np * (double)total < 1.5e10) first = np;
+    // (RT_AMD_RANGE_MIN_WORK, read at every call: tests set it to 0 to run ranges on small inputs)
+    const char* min_work_env = getenv("RT_AMD_RANGE_MIN_WORK");
+    const double min_work = min_work_env ? atof(min_work_env) : 1.5e10;
+    if ((double)np * (double)total < min_work) first = np;
     int begin = 0, len = first, cur = 0;
     bool indexed = binned;
     // a long sweep of binned rays (they all end at their light): order every set by direction

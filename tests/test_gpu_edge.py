@@ -337,3 +337,32 @@ def test_every_shape_of_the_any_hit_sweep(shape, monkeypatch):
     assert np.array_equal(out["hit"], ref["hit"])
     assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
     sc.close()
+
+
+@pytest.mark.parametrize("apex_shape", [None, "8,3", "2,5"])
+def test_ranged_any_hit_sweeps_on_a_small_scene(apex_shape, monkeypatch):
+    """Large frames sweep the shadow rays in triangle ranges with the survivors compacted (and
+    sorted by direction) in between; small inputs take one launch.  Force the ranged path on a
+    scene the oracle can shade completely: 10 000 triangles = 79 tiles = ranges of 16, 32 and 31
+    tiles, four lights (one inside the mesh, one far away)."""
+    monkeypatch.setenv("RT_AMD_RANGE_MIN_WORK", "0")
+    if apex_shape:
+        monkeypatch.setenv("RT_AMD_APEX_FORCE", apex_shape)
+    mesh = scenes.triangle_soup(10000, seed=21)
+    fr = kernel.driver_frame(9)
+    for k, pos in enumerate([(0.5, 0.2, 12.0), (300.0, -200.0, 150.0)]):
+        l = fr.num_lights
+        for c in range(3):
+            fr.light_in_eye_space[l][c] = pos[c]
+            fr.light_rgb[l][c] = 0.5
+        fr.light_attenuation[l][0] = fr.light_attenuation[l][1] = 0.0
+        fr.light_max_dist[l] = 1e9
+        fr.num_lights = l + 1
+    W, H = 160, 90
+    ref, _ = _ref(mesh, fr, W, H)
+    sc, out = _gpu(mesh, fr, W, H)
+    assert ref["shadow_rays"] > 20000
+    assert np.array_equal(out["hit"], ref["hit"])
+    d = np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int))
+    assert d.max() <= 1
+    sc.close()
