@@ -158,24 +158,29 @@ def main() -> None:
     frame = frames[0]
     step_no = [0]
     sc = kernel.Scene(mesh, device=local_rank)
-    # rows are dealt to the ranks in interleaved blocks of 16 (one rank: the whole image)
-    my_rows = parallel.part_rows(H, world, rank)
+    # A frame sequence is split by frames: rank r renders frames r, r + world, ... whole, and
+    # nothing is exchanged (driver.c:196-199 writes one picture per frame; so would every rank).
+    frame_parallel = sequence and world > 1
+    # Otherwise rows are dealt to the ranks in interleaved blocks of 16 (one rank: the whole image)
+    my_rows = parallel.part_rows(H, 1, 0) if frame_parallel else parallel.part_rows(H, world, rank)
     rows = kernel.rows_count(my_rows)
-    max_rows = parallel.max_part_rows(H, world)
+    max_rows = rows if frame_parallel else parallel.max_part_rows(H, world)
     # outputs live in HBM for the whole run; the gather buffer is padded to the largest part
     out = {"hit": torch.empty((rows, W), dtype=torch.int32, device=dev),
            "rgb8": torch.zeros((max_rows, W, 3), dtype=torch.uint8, device=dev)}
     gathered = ([torch.empty((max_rows, W, 3), dtype=torch.uint8, device=dev) for _ in range(world)]
                 if (use_dist and rank == 0) else None)
-    screen = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
+    screen = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) if (rank == 0 or frame_parallel) else None
 
     def step():
-        k = step_no[0] % len(frames)
+        k = (step_no[0] * world + rank if frame_parallel else step_no[0]) % len(frames)
         step_no[0] += 1
         sc.transform(obmats[k])                   # driver.c:110 on the device-resident mesh
         sc.render_rows(frames[k], W, H, TAN_HALF, want=("hit", "rgb8"), rows_set=my_rows,
                        out={"hit": out["hit"], "rgb8": out["rgb8"][:rows]})
-        if use_dist:
+        if frame_parallel:
+            sc.place_rows(out["rgb8"], W, H, screen=screen, rows_set=my_rows)
+        elif use_dist:
             if args.backend == "gloo":
                 host = [torch.empty(out["rgb8"].shape, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
                 dist.gather(out["rgb8"].cpu(), host, dst=0)
@@ -251,16 +256,17 @@ def main() -> None:
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": wall / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if frame_parallel else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "mesh": mesh.name, "triangles": mesh.num_tris,
                        "width": W, "height": H, "lights": frame.num_lights,
-                       "sharding": (f"{world} interleaved row parts (16-row blocks), "
+                       "sharding": f"{world} ranks, one whole frame each per step (frames rank, rank + {world}, ...), no exchange"
+                       if frame_parallel else (f"{world} interleaved row parts (16-row blocks), "
                                     f"{'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} gather to rank 0")
                        if world > 1 else "single GPU"},
-            "frames_per_s": steps / wall,
+            "frames_per_s": steps * (world if frame_parallel else 1) / wall,
             "primary_mrays_per_s": rays_p / (wall / steps) / 1e6,
             "rays_per_frame": {"primary": rays_p, "shadow": rays_s},
             "tests_per_s": tests / (wall / steps),
@@ -303,7 +309,7 @@ def main() -> None:
             },
         }
         if args.verify:
-            k = (step_no[0] - 1) % len(frames)
+            k = ((step_no[0] - 1) * world + rank if frame_parallel else step_no[0] - 1) % len(frames)
             sc.transform(obmats[k])
             alone = sc.render_rows(frames[k], W, H, TAN_HALF, want=("rgb8",))["rgb8"]
             res["verify"] = {"screen_equals_single_rank_render":

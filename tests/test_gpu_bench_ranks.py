@@ -35,3 +35,17 @@ def test_rccl_gather_with_one_rank():
     d = _bench([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--workload",
                 "teapot_class_480p", "--force-dist", "--verify", "--no-cpu-baseline"])
     assert d["verify"]["screen_equals_single_rank_render"] is True
+
+
+def test_frame_sequence_is_split_by_frames():
+    """A frame sequence under several ranks: every rank renders whole frames (rank, rank + world,
+    ...) and nothing is exchanged; rank 0's last picture equals a single-rank render of that
+    frame and the frame rate counts every rank's frames."""
+    d = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", "29549", "bench.py", "--gpus", "2",
+                "--steps", "2", "--warmup", "1", "--workload", "teapot_seq_4k", "--backend", "gloo",
+                "--verify", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["verify"]["screen_equals_single_rank_render"] is True
+    assert d["rays_per_frame"]["primary"] == 2 * 3840 * 2160          # two frames per step
+    assert abs(d["frames_per_s"] * d["ms_per_step"] * 1e-3 - 2.0) < 1e-6
