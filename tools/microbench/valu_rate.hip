@@ -53,6 +53,41 @@ KERNEL2(k_pk_add, "v_pk_add_f32 %0, %0, %8\n" "v_pk_add_f32 %1, %1, %8\n" "v_pk_
 KERNEL2(k_pk_fma, "v_pk_fma_f32 %0, %0, %8, %9\n" "v_pk_fma_f32 %1, %1, %8, %9\n" "v_pk_fma_f32 %2, %2, %8, %9\n" "v_pk_fma_f32 %3, %3, %8, %9\n" "v_pk_fma_f32 %4, %4, %8, %9\n" "v_pk_fma_f32 %5, %5, %8, %9\n" "v_pk_fma_f32 %6, %6, %8, %9\n" "v_pk_fma_f32 %7, %7, %8, %9\n" )
 KERNEL2(k_pk_mul, "v_pk_mul_f32 %0, %0, %8\n" "v_pk_mul_f32 %1, %1, %8\n" "v_pk_mul_f32 %2, %2, %8\n" "v_pk_mul_f32 %3, %3, %8\n" "v_pk_mul_f32 %4, %4, %8\n" "v_pk_mul_f32 %5, %5, %8\n" "v_pk_mul_f32 %6, %6, %8\n" "v_pk_mul_f32 %7, %7, %8\n" )
 
+#define KERNEL1(name, body)                                                                       \
+    __global__ void __launch_bounds__(256) name(float* out, int iters, float a, float b)         \
+    {                                                                                             \
+        float v0 = threadIdx.x, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3, v4 = v0 + 4, v5 = v0 + 5,  \
+              v6 = v0 + 6, v7 = v0 + 7;                                                            \
+        for (int i = 0; i < iters; ++i)                                                           \
+            asm volatile(body                                                                     \
+                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6),  \
+                           "+v"(v7)                                                               \
+                         : "v"(a), "v"(b) : "vcc");                                               \
+        out[blockIdx.x * 256 + threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;              \
+    }
+// the hot loop of the pixel-grid sweep for one triangle and 16 pixels, and of the any-hit sweep for
+// one triangle and 8 rays (no LDS reads, no branch): what the instruction mix alone costs
+KERNEL1(k_raster16, "v_fma_f32 %0, %8, %9, %0\n" "v_fma_f32 %1, %8, %9, %1\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_b32 %4, %2, %3\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_cmp_gt_i32 vcc, 0, %4\n" )
+KERNEL1(k_apex8, "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %5, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %6, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %7, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %5, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %6, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %7, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %5, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %6, %2, %3, %0\n" "v_max_f32 %4, %5, %6\n" "v_max3_f32 %4, %4, %7, %5\n" "v_max3_f32 %4, %4, %6, %7\n" "v_max3_f32 %4, %4, %5, %6\n" "v_cmp_le_f32 vcc, 0, %4\n" )
+template <class K>
+void run_mix(const char* name, K k, float* out, int wgs, int instrs, int pairs)
+{
+    const int iters = 40000;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k, dim3(wgs), dim3(256), 0, 0, out, iters / 4, 1.0001f, 0.5f);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(wgs), dim3(256), 0, 0, out, iters, 1.0001f, 0.5f);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double waves = (double)wgs * 4, s = ms * 1e-3;
+    printf("%-16s %8.3f ms  %d instructions per %d pairs: %.2f cycles per wave-instr at 2.4 GHz, %.3e pairs/s\n",
+           name, ms, instrs, pairs, 2.4e9 * 1024 / (waves * iters * instrs / s), waves * iters * 64.0 * pairs / s);
+}
+
 template <class K>
 void run(const char* name, K k, float* out, int wgs)
 {
@@ -101,6 +136,8 @@ int main()
     run("pk_fma", k_pk_fma, out, wgs);
     run("pk_mul", k_pk_mul, out, wgs);
     run("add", k_add, out, wgs);
+    run_mix("raster16", k_raster16, out, wgs, 51, 16);
+    run_mix("apex8", k_apex8, out, wgs, 45, 8);
     (void)hipFree(out);
     return 0;
 }
