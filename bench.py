@@ -104,6 +104,20 @@ def cpu_baseline(mesh, frame, W, H, budget_s: float = 15.0):
     }
 
 
+def mix_alone(pixels_per_lane: int, tests_per_s: float) -> dict:
+    """Speed of light of the primary sweep's instruction mix, from the committed micro-benchmark
+    output (16 pixels per lane only)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "valu_rate_gfx950.txt")
+    if pixels_per_lane != 16 or not os.path.exists(path):
+        return {}
+    for line in open(path):
+        if line.startswith("raster16"):
+            rate = float(line.split()[-2])
+            return {"mix_alone_tests_per_s": rate, "frac_of_mix_alone": tests_per_s / rate,
+                    "mix_alone_source": "profiles/valu_rate_gfx950.txt"}
+    return {}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,7 +311,10 @@ def main() -> None:
                                                          "logic": n_logic, "compare": n_cmp},
                                "achieved": tests_per_s_launch * instr_per_test / 1e12,
                                "peak": PEAK_VALU_TINSTR, "unit": "T lane-instr/s",
-                               "frac": tests_per_s_launch * instr_per_test / 1e12 / PEAK_VALU_TINSTR},
+                               "frac": tests_per_s_launch * instr_per_test / 1e12 / PEAK_VALU_TINSTR,
+                               # the same instruction sequence with nothing around it (no LDS reads,
+                               # barriers, branches or rare path), measured by tools/microbench/valu_rate
+                               **mix_alone(mix_ppl, tests_per_s_launch)},
                 "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
                 # the 46 flop of a general Moller-Trumbore test with its divisions, for reference only:
