@@ -792,7 +792,7 @@ static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E
 // Shadow rays of the pixel loop: [light][pixel] rays that end at their light (k_shadow_setup).
 // Apex sweeps over planes packed relative to each light (rt_sweep_apex.hip), RT_APEX_LIGHTS
 // lights per launch; the rays of a light are binned by the dominant axis of their direction.
-static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows,
+static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, int row_block,
                              const double* S, const double* E, uint8_t* occ)
 {
     hipStream_t st = rt_g().stream;
@@ -862,7 +862,7 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows,
                 const int coarser = RT_SHADOW_STEPS[level - 1];
                 RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, step, coarser, act2, live2, st));
                 RT_TRY(rt_launch_try_cached(exact_of(sc), a.S, a.E, act2, live2, sets, (int)npix, (long)npix,
-                                            W, nrows, coarser, record, a.cnt, occ_id, st));
+                                            W, nrows, row_block, coarser, record, a.cnt, occ_id, st));
                 RT_TRY(rt_launch_compact(a.cnt, act2, live2, (int)npix, sets, (long)npix, 3, act0, live0, st));
             }
             RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
@@ -943,7 +943,8 @@ static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, doubl
         a.shS = sc->ws_shS.as<double>(); a.shE = sc->ws_shE.as<double>();
         a.occ = sc->ws_occ.as<uint8_t>();
         RT_TRY(rt_launch_shadow_setup(a, st));
-        RT_TRY(trace_shadow_rays(sc, f, W, rows.rows, a.shS, a.shE, sc->ws_occ.as<uint8_t>()));
+        RT_TRY(trace_shadow_rays(sc, f, W, rows.rows, rows.parts > 1 ? rows.block : rows.rows, a.shS, a.shE,
+                                 sc->ws_occ.as<uint8_t>()));
     }
     RT_TRY(rt_launch_shade_final(a, st));
     RT_HIP(hipStreamSynchronize(st));

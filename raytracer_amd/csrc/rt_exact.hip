@@ -366,7 +366,8 @@ k_overflow_merge(RAYS rays, const int32_t* __restrict__ ovf, const int* __restri
 __global__ void __launch_bounds__(RT_WG)
 k_try_cached(ExactScene es, const double* __restrict__ Sa, const double* __restrict__ Ea,
              const int32_t* __restrict__ lists, const int* __restrict__ counts, long stride, int W,
-             int rows, int step, int record, int32_t* __restrict__ cnt, int32_t* __restrict__ occ_id)
+             int rows, int row_block, int step, int record, int32_t* __restrict__ cnt,
+             int32_t* __restrict__ occ_id)
 {
     const long set = blockIdx.y, light = set / 3;
     const int n = counts[set];
@@ -382,14 +383,24 @@ k_try_cached(ExactScene es, const double* __restrict__ Sa, const double* __restr
         const double S[3] = {Sa[3 * (long)id], Sa[3 * (long)id + 1], Sa[3 * (long)id + 2]};
         const double E[3] = {Ea[3 * (long)id], Ea[3 * (long)id + 1], Ea[3 * (long)id + 2]};
         constexpr int NB = RT_SHADOW_NEIGHBOURS, NB2 = NB * NB, LO = (NB - 2) / 2;
+        // The sample rows come from the ray's own block of rows: with interleaved row parts
+        // the next block of local rows lies elsewhere in the image.  The window of NB sample
+        // rows around the ray is shifted to stay inside the block where the block is tall enough.
+        const int b0 = lr - lr % row_block;
+        const int b1 = b0 + row_block < rows ? b0 + row_block : rows;
+        const int first = (b0 + step - 1) / step * step;                 // first sample row of the block
+        const int last = (b1 - 1) / step * step;                         // last one
+        int wy = sy - LO * step;
+        if (wy + (NB - 1) * step > last) wy = last - (NB - 1) * step;
+        if (wy < first) wy = first;
         int tried[NB2];
 #pragma unroll
         for (int k = 0; k < NB2; ++k) tried[k] = -1;
 #pragma unroll
         for (int k = 0; k < NB2; ++k) {
             const int kx = k % NB, ky = k / NB;
-            const int qx = sx + (kx - LO) * step, qy = sy + (ky - LO) * step;
-            if (qx < 0 || qy < 0 || qx >= W || qy >= rows) continue;
+            const int qx = sx + (kx - LO) * step, qy = wy + ky * step;
+            if (qx < 0 || qx >= W || qy > last) continue;
             const int t = occ_id[(long)qy * W + qx];
             if (t < 0 || t >= es.num_tris) continue;
             bool seen = false;
@@ -552,13 +563,13 @@ int rt_launch_overflow_rays(const ExactScene& es, const double* S, const double*
 
 int rt_launch_try_cached(const ExactScene& es, const double* S, const double* E, const int32_t* lists,
                          const int* counts, int sets, int n_max, long stride, int W, int rows,
-                         int step, bool record, int32_t* cnt, int32_t* occ_id, hipStream_t st)
+                         int row_block, int step, bool record, int32_t* cnt, int32_t* occ_id, hipStream_t st)
 {
     if (n_max <= 0 || sets <= 0) return RT_OK;
     long wgs = ((long)n_max + RT_WG - 1) / RT_WG;
     if (wgs > 4096) wgs = 4096;
     hipLaunchKernelGGL(k_try_cached, dim3((unsigned)wgs, sets), dim3(RT_WG), 0, st, es, S, E, lists, counts,
-                       stride, W, rows, step, record ? 1 : 0, cnt, occ_id);
+                       stride, W, rows, row_block > 0 ? row_block : rows, step, record ? 1 : 0, cnt, occ_id);
     return launched("try_cached");
 }
 

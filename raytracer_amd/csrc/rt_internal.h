@@ -294,7 +294,8 @@ int rt_launch_overflow_rays(const ExactScene& es, const double* S, const double*
 // is marked occluded in cnt[] on success.
 int rt_launch_try_cached(const ExactScene& es, const double* S, const double* E, const int32_t* lists,
                          const int* counts, int sets, int n_max, long stride, int W, int rows,
-                         int step, bool record, int32_t* cnt, int32_t* occ_id, hipStream_t st);
+                         int row_block, int step, bool record, int32_t* cnt, int32_t* occ_id,
+                         hipStream_t st);
 int rt_launch_single_ray(const ExactScene& es, const double* S_E_dev, double* out_dev,
                          hipStream_t st);
 
