@@ -606,6 +606,9 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     a.best_hi = sc->ws_besthi.as<float>();
     a.chunks = chunks; a.chunk_stride = (long)npix;
     a.tests = nullptr;
+#ifdef RT_RASTER_CHECK_INTERVAL
+    a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
+#endif
     a.tri_begin = 0; a.tri_end = sc->num_tris_padded;
     const int tiles_x = (W + 16 * rpl - 1) / (16 * rpl);
     const int tiles_y = (rows.rows + RT_TILE_H - 1) / RT_TILE_H;
@@ -614,6 +617,13 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     g.last_raster_chunks = chunks;
     RT_TRY(timed_sweep([&] { return rt_launch_sweep_raster(a, st); }, false, tests, nullptr));
     g.prof.rays_primary += npix;
+#ifdef RT_RASTER_CHECK_INTERVAL
+    {
+        unsigned long long t = 0;
+        RT_HIP(hipMemcpy(&t, a.tests, sizeof t, hipMemcpyDeviceToHost));
+        fprintf(stderr, "rt_amd: interval check: %llu slab passes outside the interval\n", t >> 48);
+    }
+#endif
 
     const ExactScene es = exact_of(sc);
     int* counters = sc->ws_counters.as<int>();

@@ -49,6 +49,9 @@
 #ifndef RT_RASTER_UNROLL
 #define RT_RASTER_UNROLL 4
 #endif
+#ifndef RT_RASTER_CHECK_INTERVAL
+#define RT_RASTER_CHECK_INTERVAL 0   // debug: count slab passes the rare path's interval would miss
+#endif
 #ifndef RT_RASTER_WAVES
 #define RT_RASTER_WAVES RT_MIN_WAVES    // waves per SIMD the pixel-grid sweep must fit
 #endif
@@ -186,24 +189,49 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
                 acc = (__float_as_int(un) & __float_as_int(wn)) | acc;      // v_and_or_b32
             }
             if (__builtin_expect(acc < 0, 0)) {
-                // Which pixels: evaluated again, each from its own X (not kept in the hot loop).
-                // Hardly ever more than one per lane, so every lane finishes its first one and
-                // the wave repeats while some lane has another.
-                unsigned pass = 0;
+                // Which pixels.  un and wn are linear along the lane's pixels, so the pixels where
+                // both are negative form one interval; its ends come from two divisions, and
+                // only the pixels inside it are evaluated again, each from its own X with the
+                // FMAs that decide (not kept in the hot loop).  The interval is a superset: a
+                // pixel whose FMA value is negative has a negative exact value, and the model
+                // u0 + r d differs from the exact value by the one rounding of u0.
+                const float u0 = __builtin_fmaf(Xs0, cur.P.x, yu), w0 = __builtin_fmaf(Xs0, cur.Q.x, yw);
+                float lo = 0.0f, hi = (float)(R - 1);
+                {
+                    const float d = cur.P.x + 0.0f;         // -0 counts as +0
+                    const float q = __builtin_fmaf(U22, __builtin_fabsf(u0), -u0) * __builtin_amdgcn_rcpf(d);
+                    if (d < 0.0f) lo = __builtin_fmaxf(lo, q - 0.001f);      // r d < tol - u0  <=>  r > q
+                    else hi = __builtin_fminf(hi, q + 0.001f);               //                 <=>  r < q
+                }
+                {
+                    const float d = cur.Q.x + 0.0f;
+                    const float q = __builtin_fmaf(U22, __builtin_fabsf(w0), -w0) * __builtin_amdgcn_rcpf(d);
+                    if (d < 0.0f) lo = __builtin_fmaxf(lo, q - 0.001f);
+                    else hi = __builtin_fminf(hi, q + 0.001f);
+                }
+                // (a NaN quotient leaves its bound alone: fmin / fmax return the other operand)
+                int r = (int)__builtin_ceilf(__builtin_fminf(lo, (float)R));
+                const int r_hi = (int)__builtin_floorf(__builtin_fmaxf(hi, -1.0f));
+#if RT_RASTER_CHECK_INTERVAL
+                {
+                    unsigned pass = 0;
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
+                    for (int k = 0; k < R; ++k) {
+                        const float Xs = Xs0 + (float)k;
+                        const float u1 = __builtin_fmaf(Xs, cur.P.x, yu);
+                        const float w1 = __builtin_fmaf(Xs, cur.Q.x, yw);
+                        pass |= ((unsigned)(__float_as_int(u1) & __float_as_int(w1)) >> 31) << k;
+                    }
+                    const unsigned inside = r > r_hi ? 0u : ((r_hi >= 31 ? ~0u : (2u << r_hi) - 1u) & ~((1u << r) - 1u));
+                    if ((pass & ~inside) && A.tests) atomicAdd(A.tests, 1ull << 48);
+                }
+#endif
+                for (; r <= r_hi; ++r) {
                     const float Xs = Xs0 + (float)r;
                     const float u1 = __builtin_fmaf(Xs, cur.P.x, yu);
                     const float w1 = __builtin_fmaf(Xs, cur.Q.x, yw);
-                    pass |= ((unsigned)(__float_as_int(u1) & __float_as_int(w1)) >> 31) << r;
-                }
-                pass &= on_image;
-                while (pass) {
-                    const int rs = __builtin_ctz(pass);
-                    pass &= pass - 1;
-                    const float Xs = Xs0 + (float)rs;
-                    finish_raster(A, slot0 + COLS * rs, tri0 + j, cur, base + j, Xs, Y,
-                                  __builtin_fmaf(Xs, cur.P.x, yu));
+                    if ((__float_as_int(u1) & __float_as_int(w1)) < 0 && ((on_image >> r) & 1u))
+                        finish_raster(A, slot0 + COLS * r, tri0 + j, cur, base + j, Xs, Y, u1);
                 }
             }
         }
