@@ -43,6 +43,9 @@
 #ifndef RT_APEX_POLL
 #define RT_APEX_POLL 16     // tiles between looks at the flags other chunks may have set (power of two)
 #endif
+#ifndef RT_APEX_ROUNDS
+#define RT_APEX_ROUNDS 16    // rounds of workgroups an any-hit launch is cut into (triangle chunks)
+#endif
 #ifndef RT_APEX_UNROLL
 #define RT_APEX_UNROLL 4
 #endif
@@ -743,11 +746,11 @@ static int apex_rays_per_lane(long n, int max_chunks)
 }
 
 // Triangle chunks of an any-hit launch of `wgs` workgroups in total: enough to give the machine
-// about 8 rounds of work.
+// about RT_APEX_ROUNDS rounds of work.
 static int apex_chunks(long wgs, int max_chunks)
 {
     const long slots = 5L * device_cus();
-    long c = (8 * slots + wgs - 1) / wgs;
+    long c = (RT_APEX_ROUNDS * slots + wgs - 1) / wgs;
     if (c > max_chunks) c = max_chunks;
     return c < 1 ? 1 : (int)c;
 }
