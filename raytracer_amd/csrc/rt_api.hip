@@ -581,8 +581,8 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     RtGlobal& g = rt_g();
     hipStream_t st = g.stream;
     const size_t npix = (size_t)W * rows.rows;
-    int rpl = 1, chunks = 1;
-    rt_raster_shape(W, rows.rows, sc->num_tris_padded / RT_TILE, &rpl, &chunks);
+    int rpl = 1, chunks = 1, waves_x = 4;
+    rt_raster_shape(W, rows.rows, sc->num_tris_padded / RT_TILE, &rpl, &chunks, &waves_x);
     const size_t slots = npix * (size_t)chunks;
     RT_TRY(workspaces(sc, slots));
     RT_TRY(sc->ws_besthi.reserve(sizeof(float) * slots));
@@ -605,14 +605,14 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     a.cnt = sc->ws_cnt.as<int32_t>(); a.list = sc->ws_list.as<int32_t>();
     a.best_hi = sc->ws_besthi.as<float>();
     a.chunks = chunks; a.chunk_stride = (long)npix;
+    a.waves_x = waves_x;
     a.tests = nullptr;
 #ifdef RT_RASTER_CHECK_INTERVAL
     a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
 #endif
     a.tri_begin = 0; a.tri_end = sc->num_tris_padded;
-    const int tiles_x = (W + 16 * rpl - 1) / (16 * rpl);
-    const int tiles_y = (rows.rows + RT_TILE_H - 1) / RT_TILE_H;
-    const uint64_t tests = (uint64_t)tiles_x * tiles_y * (RT_WG * rpl) * (uint64_t)sc->num_tris_padded;
+    const uint64_t tests = (uint64_t)rt_raster_tiles(W, rows.rows, rpl, waves_x) * (RT_WG * rpl) *
+                           (uint64_t)sc->num_tris_padded;
     g.last_raster_rpl = rpl;
     g.last_raster_chunks = chunks;
     RT_TRY(timed_sweep([&] { return rt_launch_sweep_raster(a, st); }, false, tests, nullptr));

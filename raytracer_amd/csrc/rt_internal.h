@@ -226,6 +226,7 @@ struct SweepArgs {
     // separate workgroups; chunk c keeps its counts and lists chunk_stride rays further on
     int chunks;
     long chunk_stride;
+    int waves_x;            // pixel-grid sweep only: waves side by side in a workgroup tile (4, 2, 1)
     // pixel-grid sweep only: per ray and chunk, the upper bound of the closest certain hit's t
     // so far (+inf before the sweep); cnt[] must be zero before the sweep
     float* best_hi;
@@ -237,7 +238,15 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st);   // primary ray
 // launch shape of the pixel-grid sweep for a band of W x rows pixels and `tiles` triangle tiles:
 // pixels per lane (<= RT_RASTER_RPL) and the number of triangle chunks (<= RT_RASTER_MAX_CHUNKS)
 constexpr int RT_RASTER_MAX_CHUNKS = 24;
-void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks);
+// and how the four waves of a workgroup are laid out: waves_x (4, 2 or 1) side by side, the rest
+// below, i.e. workgroup tiles of (waves_x * RT_RASTER_COLS * pixels_per_lane) x (64 / waves_x) pixels
+void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks, int* waves_x);
+// workgroup tiles that shape needs to cover W x rows pixels
+inline long rt_raster_tiles(int W, int rows, int pixels_per_lane, int waves_x)
+{
+    const int tw = waves_x * RT_RASTER_COLS * pixels_per_lane, th = RT_TILE_H * (4 / waves_x);
+    return (long)((W + tw - 1) / tw) * ((rows + th - 1) / th);
+}
 int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st);     // any-hit over binned ray lists
 // shadow rays [light][pixel] -> ray-number lists per (light, dominant axis), stride entries apart
 // Only the rays of pixels whose column and local row are multiples of step_in, and not both

@@ -127,15 +127,18 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    // workgroup = (16 R) x 16 pixels, its four waves side by side; wave = (COLS R) x (64 / COLS)
-    // pixels; lane = one row, R pixels COLS apart.  (The squarer a wave's pixels, the fewer
+    // wave = (COLS R) x (64 / COLS) pixels; lane = one row, R pixels COLS apart; workgroup = its
+    // four waves side by side ((16 R) x 16 pixels), two by two or stacked.  (The squarer a wave's pixels, the fewer
     // triangles have one of them in their slab: the rare path is paid per wave.)
     constexpr int COLS = RT_RASTER_COLS;
-    static_assert(4 * COLS == 16 && 64 / COLS == RT_TILE_H, "workgroup tile is (16 R) x RT_TILE_H pixels");
-    const int tiles_x = (A.W + 16 * R - 1) / (16 * R);
+    static_assert(64 / COLS == RT_TILE_H, "a wave covers RT_TILE_H rows");
+    // the four waves: waves_x side by side, the rest below (whichever wastes fewer pixels beyond
+    // the image's right and bottom edges)
+    const int wx = A.waves_x, tile_w = wx * (COLS * R), tile_h = RT_TILE_H * (4 / wx);
+    const int tiles_x = (A.W + tile_w - 1) / tile_w;
     const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int px0 = txi * (16 * R) + wave * (COLS * R) + (lane % COLS);
-    const int lr = tyi * RT_TILE_H + lane / COLS;                  // local row of the call's row set
+    const int px0 = txi * tile_w + (wave & (wx - 1)) * (COLS * R) + (lane % COLS);
+    const int lr = tyi * tile_h + (wave / wx) * RT_TILE_H + lane / COLS;    // local row of the call's row set
     const float Y = (float)(A.rows.image_row(lr) - A.H / 2);        // driver.c:132
     // ray number: local pixel, in the segment of this workgroup's triangle chunk
     const long slot0 = (long)blockIdx.y * A.chunk_stride + (long)lr * A.W + px0;
@@ -648,38 +651,52 @@ static int device_cus()
 // 8 chunks instead of 1 take 6 % off a 3840x2160 sweep and 33 % off a 3840x270 one, at the
 // price of three times as many candidates for the exact pass (less pruning across chunks).
 // A chunk keeps at least 8 tiles; a mesh too small to fill the machine that way gives up
-// pixels per lane instead.  RT_AMD_RASTER_FORCE="<pixels per lane>,<chunks>" overrides the
-// choice (read at every call: tests use it to run every kernel shape on small inputs).
-void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks)
+// pixels per lane instead.  RT_AMD_RASTER_FORCE="<pixels per lane>,<chunks>[,<waves side by
+// side>]" overrides the choice (read at every call: tests use it to run every kernel shape on
+// small inputs).
+void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks, int* waves_x)
 {
     const long slots = 5L * device_cus();           // resident workgroups
-    const long tiles_y = (rows + RT_TILE_H - 1) / RT_TILE_H;
     int max_chunks = tiles / 8;
     if (max_chunks < 1) max_chunks = 1;
     static const int cap = getenv("RT_AMD_RASTER_MAX_CHUNKS") ? atoi(getenv("RT_AMD_RASTER_MAX_CHUNKS")) : RT_RASTER_MAX_CHUNKS;
     if (max_chunks > cap) max_chunks = cap;
+    // pixels the workgroup tiles cover, and the wave layout that covers the fewest
+    auto covered = [&](int r, int wx) {
+        const long tw = (long)wx * RT_RASTER_COLS * r, th = RT_TILE_H * (4 / wx);
+        return ((W + tw - 1) / tw) * tw * (((rows + th - 1) / th) * th);
+    };
+    auto best_layout = [&](int r) {
+        int wx = 4;
+        if (covered(r, 2) < covered(r, wx)) wx = 2;
+        if (covered(r, 1) < covered(r, wx)) wx = 1;
+        return wx;
+    };
     if (const char* force = getenv("RT_AMD_RASTER_FORCE")) {
-        int fr = 0, fc = 0;
-        if (sscanf(force, "%d,%d", &fr, &fc) == 2 && fc >= 1 && fc <= (tiles < 1 ? 1 : tiles) &&
+        int fr = 0, fc = 0, fw = 0;
+        const int n = sscanf(force, "%d,%d,%d", &fr, &fc, &fw);
+        if (n >= 2 && fc >= 1 && fc <= (tiles < 1 ? 1 : tiles) &&
             (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == RT_RASTER_RPL)) {
             *pixels_per_lane = fr;
             *chunks = fc;
+            *waves_x = (n == 3 && (fw == 1 || fw == 2 || fw == 4)) ? fw : best_layout(fr);
             return;
         }
     }
     int r = RT_RASTER_RPL;
-    while (r > 1 && 16 * r > W + 8 * r) r /= 2;         // no lane set mostly off the image
-    // 16 pixels per lane save 3 % over 8 (measured), less than a half-empty last tile column costs
-    auto padded = [&](int rr) { return (long)((W + 16 * rr - 1) / (16 * rr)) * (16 * rr); };
-    if (r == 16 && padded(16) * 100 > padded(8) * 102) r = 8;
+    while (r > 1 && RT_RASTER_COLS * r > W + RT_RASTER_COLS * r / 2) r /= 2;    // no wave mostly off the image
+    // 16 pixels per lane save 3 % over 8 (measured), less than half-empty tiles at the edges cost
+    if (r == 16 && covered(16, best_layout(16)) * 100 > covered(8, best_layout(8)) * 102) r = 8;
     for (;;) {
-        const long wgs = (long)((W + 16 * r - 1) / (16 * r)) * tiles_y;
+        const int wx = best_layout(r);
+        const long wgs = rt_raster_tiles(W, rows, r, wx);
         if (wgs * max_chunks >= slots || r == 1) {
             long c = (24 * slots + wgs - 1) / wgs;      // about 24 rounds are fine-grained enough
             if (c > max_chunks) c = max_chunks;
             if (c < 1) c = 1;
             *pixels_per_lane = r;
             *chunks = (int)c;
+            *waves_x = wx;
             return;
         }
         r /= 2;
@@ -698,16 +715,14 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
         rt_set_error("raster sweep: null buffer");
         return RT_E_ARG;
     }
-    int r = 1, chunks = 1;
-    rt_raster_shape(a.W, a.rows.rows, (a.tri_end - a.tri_begin) / RT_TILE, &r, &chunks);
-    if (a.chunks != chunks || (chunks > 1 && a.chunk_stride < (long)a.W * a.rows.rows)) {
-        rt_set_error("raster sweep: caller and launcher disagree on the chunk count (%d vs %d)",
-                     a.chunks, chunks);
+    int r = 1, chunks = 1, wx = 4;
+    rt_raster_shape(a.W, a.rows.rows, (a.tri_end - a.tri_begin) / RT_TILE, &r, &chunks, &wx);
+    if (a.chunks != chunks || a.waves_x != wx || (chunks > 1 && a.chunk_stride < (long)a.W * a.rows.rows)) {
+        rt_set_error("raster sweep: caller and launcher disagree on the launch shape (%d chunks, %d waves "
+                     "side by side vs %d, %d)", a.chunks, a.waves_x, chunks, wx);
         return RT_E_ARG;
     }
-    const int tiles_x = (a.W + 16 * r - 1) / (16 * r);
-    const int tiles_y = (a.rows.rows + RT_TILE_H - 1) / RT_TILE_H;
-    const dim3 grid(tiles_x * tiles_y, chunks);
+    const dim3 grid((unsigned)rt_raster_tiles(a.W, a.rows.rows, r, wx), chunks);
     switch (r) {
     case 1: return launch(k_sweep_raster<1>, a, grid, st, "raster sweep");
     case 2: return launch(k_sweep_raster<2>, a, grid, st, "raster sweep");

@@ -303,13 +303,13 @@ def test_triangles_whose_plane_contains_the_eye(through_eye):
     sc.close()
 
 
-@pytest.mark.parametrize("shape", ["16,1", "16,3", "8,2", "4,1", "2,5", "1,1"])
+@pytest.mark.parametrize("shape", ["16,1", "16,3", "8,2", "4,1", "2,5", "1,1", "16,2,2", "16,1,1", "8,3,1", "4,2,2"])
 @pytest.mark.parametrize("W,H", [(500, 20), (37, 19)])
 def test_every_shape_of_the_pixel_grid_sweep(shape, W, H, monkeypatch):
     """The launcher picks pixels per lane and triangle chunks from the image and mesh size, so
     small inputs never reach the shapes large frames run with: force each one (lanes whose
-    pixels are partly or wholly off the image, chunks of uneven length) and compare with the
-    oracle."""
+    pixels are partly or wholly off the image, chunks of uneven length, the four waves of a
+    workgroup side by side, two by two or stacked) and compare with the oracle."""
     monkeypatch.setenv("RT_AMD_RASTER_FORCE", shape)
     mesh = scenes.triangle_soup(700, seed=5)
     fr = kernel.driver_frame(4)
