@@ -106,12 +106,12 @@ def cpu_baseline(mesh, frame, W, H, budget_s: float = 15.0):
 
 def mix_alone(pixels_per_lane: int, tests_per_s: float) -> dict:
     """Speed of light of the primary sweep's instruction mix, from the committed micro-benchmark
-    output (16 pixels per lane only)."""
+    output (16 and 32 pixels per lane)."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "valu_rate_gfx950.txt")
-    if pixels_per_lane != 16 or not os.path.exists(path):
+    if not os.path.exists(path):
         return {}
     for line in open(path):
-        if line.startswith("raster16"):
+        if line.split()[:1] == [f"raster{pixels_per_lane}"]:
             rate = float(line.split()[-2])
             return {"mix_alone_tests_per_s": rate, "frac_of_mix_alone": tests_per_s / rate,
                     "mix_alone_source": "profiles/valu_rate_gfx950.txt"}

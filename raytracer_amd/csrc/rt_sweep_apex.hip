@@ -676,7 +676,7 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
         int fr = 0, fc = 0, fw = 0;
         const int n = sscanf(force, "%d,%d,%d", &fr, &fc, &fw);
         if (n >= 2 && fc >= 1 && fc <= (tiles < 1 ? 1 : tiles) &&
-            (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == RT_RASTER_RPL)) {
+            (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == 16 || fr == RT_RASTER_RPL) && fr <= RT_RASTER_RPL) {
             *pixels_per_lane = fr;
             *chunks = fc;
             *waves_x = (n == 3 && (fw == 1 || fw == 2 || fw == 4)) ? fw : best_layout(fr);
@@ -685,8 +685,15 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     }
     int r = RT_RASTER_RPL;
     while (r > 1 && RT_RASTER_COLS * r > W + RT_RASTER_COLS * r / 2) r /= 2;    // no wave mostly off the image
-    // 16 pixels per lane save 3 % over 8 (measured), less than half-empty tiles at the edges cost
-    if (r == 16 && covered(16, best_layout(16)) * 100 > covered(8, best_layout(8)) * 102) r = 8;
+    // more pixels per lane cost fewer instructions per pair, but their wider tiles may cover
+    // more pixels beyond the image's edges: take the cheaper product
+    while (r > 8) {
+        const RasterMix m = rt_raster_mix(r), h = rt_raster_mix(r / 2);
+        const double cost = (double)(m.fma + m.add + m.logic + m.compare) / r * covered(r, best_layout(r));
+        const double cost_half = (double)(h.fma + h.add + h.logic + h.compare) / (r / 2) * covered(r / 2, best_layout(r / 2));
+        if (cost <= cost_half) break;
+        r /= 2;
+    }
     for (;;) {
         const int wx = best_layout(r);
         const long wgs = rt_raster_tiles(W, rows, r, wx);
@@ -728,8 +735,11 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
     case 2: return launch(k_sweep_raster<2>, a, grid, st, "raster sweep");
     case 4: return launch(k_sweep_raster<4>, a, grid, st, "raster sweep");
     case 8: return launch(k_sweep_raster<8>, a, grid, st, "raster sweep");
-#if RT_RASTER_RPL > 8
-    case RT_RASTER_RPL: return launch(k_sweep_raster<RT_RASTER_RPL>, a, grid, st, "raster sweep");
+#if RT_RASTER_RPL >= 16
+    case 16: return launch(k_sweep_raster<16>, a, grid, st, "raster sweep");
+#endif
+#if RT_RASTER_RPL >= 32
+    case 32: return launch(k_sweep_raster<32>, a, grid, st, "raster sweep");
 #endif
     }
     rt_set_error("raster sweep: unsupported pixels per lane %d", r);
