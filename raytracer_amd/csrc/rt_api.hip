@@ -611,8 +611,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
 #endif
     a.tri_begin = 0; a.tri_end = sc->num_tris_padded;
-    const uint64_t tests = (uint64_t)rt_raster_tiles(W, rows.rows, rpl, waves_x) * (RT_WG * rpl) *
-                           (uint64_t)sc->num_tris_padded;
+    const uint64_t tests = (uint64_t)rt_raster_pairs(W, rows.rows, rpl, sc->num_tris_padded);
     g.last_raster_rpl = rpl;
     g.last_raster_chunks = chunks;
     RT_TRY(timed_sweep([&] { return rt_launch_sweep_raster(a, st); }, false, tests, nullptr));

@@ -241,6 +241,13 @@ constexpr int RT_RASTER_MAX_CHUNKS = 24;
 // and how the four waves of a workgroup are laid out: waves_x (4, 2 or 1) side by side, the rest
 // below, i.e. workgroup tiles of (waves_x * RT_RASTER_COLS * pixels_per_lane) x (64 / waves_x) pixels
 void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks, int* waves_x);
+// pixel-triangle pairs the working waves of that shape evaluate (a wave covers
+// RT_RASTER_COLS * pixels_per_lane x RT_TILE_H pixels; waves wholly off the image idle)
+inline long rt_raster_pairs(int W, int rows, int pixels_per_lane, long tris)
+{
+    const int ww = RT_RASTER_COLS * pixels_per_lane;
+    return (long)((W + ww - 1) / ww) * ((rows + RT_TILE_H - 1) / RT_TILE_H) * (64L * pixels_per_lane) * tris;
+}
 // workgroup tiles that shape needs to cover W x rows pixels
 inline long rt_raster_tiles(int W, int rows, int pixels_per_lane, int waves_x)
 {

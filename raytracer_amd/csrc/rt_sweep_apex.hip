@@ -137,8 +137,12 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
     const int wx = A.waves_x, tile_w = wx * (COLS * R), tile_h = RT_TILE_H * (4 / wx);
     const int tiles_x = (A.W + tile_w - 1) / tile_w;
     const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int px0 = txi * tile_w + (wave & (wx - 1)) * (COLS * R) + (lane % COLS);
-    const int lr = tyi * tile_h + (wave / wx) * RT_TILE_H + lane / COLS;    // local row of the call's row set
+    const int wave_x0 = txi * tile_w + (wave & (wx - 1)) * (COLS * R);
+    const int wave_y0 = tyi * tile_h + (wave / wx) * RT_TILE_H;
+    const int px0 = wave_x0 + (lane % COLS);
+    const int lr = wave_y0 + lane / COLS;                           // local row of the call's row set
+    // a wave that lies wholly beyond the image's right or bottom edge only helps to stage tiles
+    const bool wave_on = __builtin_amdgcn_readfirstlane((wave_x0 < A.W && wave_y0 < A.rows.rows) ? 1 : 0) != 0;
     const float Y = (float)(A.rows.image_row(lr) - A.H / 2);        // driver.c:132
     // ray number: local pixel, in the segment of this workgroup's triangle chunk
     const long slot0 = (long)blockIdx.y * A.chunk_stride + (long)lr * A.W + px0;
@@ -171,7 +175,7 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
         // basic blocks, which keeps the compiler from hoisting them)
         Tri2 next = load_tri2(base);
 #pragma unroll kRasterUnroll
-        for (int j = 0; j < RT_TILE; ++j) {
+        for (int j = 0; wave_on && j < RT_TILE; ++j) {
             const Tri2 cur = next;
             next = load_tri2(base + ((j + 1) & (RT_TILE - 1)));     // last iteration re-reads entry 0 (unused)
             // sign tests (k_pack_apex, sign layout): un = -(U + delta) and wn = -(W' + delta) of an
@@ -246,8 +250,8 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
         __syncthreads();
     }
 
-    if (A.tests && tid == 0)
-        atomicAdd(A.tests, tiles_done * (unsigned long long)RT_TILE * (RT_WG * R));
+    if (A.tests && lane == 0 && wave_on)
+        atomicAdd(A.tests, tiles_done * (unsigned long long)RT_TILE * (64 * R));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -661,11 +665,14 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     if (max_chunks < 1) max_chunks = 1;
     static const int cap = getenv("RT_AMD_RASTER_MAX_CHUNKS") ? atoi(getenv("RT_AMD_RASTER_MAX_CHUNKS")) : RT_RASTER_MAX_CHUNKS;
     if (max_chunks > cap) max_chunks = cap;
-    // pixels the workgroup tiles cover, and the wave layout that covers the fewest
+    // pixels the workgroup tiles cover, and the wave layout that covers the fewest (waves wholly
+    // beyond the image's edges do no arithmetic, but they hold registers and LDS)
     auto covered = [&](int r, int wx) {
         const long tw = (long)wx * RT_RASTER_COLS * r, th = RT_TILE_H * (4 / wx);
         return ((W + tw - 1) / tw) * tw * (((rows + th - 1) / th) * th);
     };
+    // pixels the working waves cover: what the arithmetic is paid for
+    auto swept = [&](int r) { return rt_raster_pairs(W, rows, r, 1); };
     auto best_layout = [&](int r) {
         int wx = 4;
         if (covered(r, 2) < covered(r, wx)) wx = 2;
@@ -689,9 +696,11 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     // more pixels beyond the image's edges: take the cheaper product
     while (r > 8) {
         const RasterMix m = rt_raster_mix(r), h = rt_raster_mix(r / 2);
-        const double cost = (double)(m.fma + m.add + m.logic + m.compare) / r * covered(r, best_layout(r));
-        const double cost_half = (double)(h.fma + h.add + h.logic + h.compare) / (r / 2) * covered(r / 2, best_layout(r / 2));
-        if (cost <= cost_half) break;
+        const double cost = (double)(m.fma + m.add + m.logic + m.compare) / r * swept(r);
+        const double cost_half = (double)(h.fma + h.add + h.logic + h.compare) / (r / 2) * swept(r / 2);
+        // ... unless the wider lanes leave too few workgroups for four rounds of the machine
+        const bool enough = rt_raster_tiles(W, rows, r, best_layout(r)) * max_chunks >= 4 * slots;
+        if (cost <= cost_half && enough) break;
         r /= 2;
     }
     for (;;) {
