@@ -1,0 +1,48 @@
+"""The primary sweep's rare path finds a lane's passing pixels as an interval computed from two
+divisions instead of evaluating every pixel of the lane again.  A checking build of the same
+sources (raytracer_amd/librt_amd_check.so, -DRT_RASTER_CHECK_INTERVAL=1) does both and counts
+the slab passes that lie outside the interval; there must be none, on hard scenes and for every
+lane width."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECK_LIB = os.path.join(ROOT, "raytracer_amd", "librt_amd_check.so")
+
+SCRIPT = r"""
+import math, sys
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from raytracer_amd import kernel, scenes
+import stress_parity as sp
+tan_half = math.tan(math.pi / 6)
+meshes = [scenes.triangle_soup(30000, seed=3), scenes.torus(20000)] + [make(1) for _, make in sp.CASES]
+for mesh in meshes:
+    scenes.center_and_scale(mesh)
+    for frame in (0, 17):
+        fr = kernel.driver_frame(frame)
+        sc = kernel.Scene(mesh)
+        sc.transform(kernel.frame_matrix(fr, "obmat"))
+        sc.trace_primary(1280, 352, tan_half)
+        sc.close()
+"""
+
+
+@pytest.mark.parametrize("shape", [None, "32,4,2", "16,3,4", "8,2,1"])
+def test_no_slab_pass_outside_the_interval(shape):
+    if not os.path.exists(CHECK_LIB):
+        pytest.fail("raytracer_amd/librt_amd_check.so is missing: run __graft_entry__.build()")
+    env = dict(os.environ, RT_AMD_LIB=CHECK_LIB)
+    if shape:
+        env["RT_AMD_RASTER_FORCE"] = shape
+    p = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, os.path.join(ROOT, "tools"))], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    counts = [int(m) for m in re.findall(r"interval check: (\d+) slab passes", p.stderr)]
+    assert len(counts) >= 16, p.stderr[-2000:]
+    assert sum(counts) == 0, counts
