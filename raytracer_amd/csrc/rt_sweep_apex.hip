@@ -150,10 +150,10 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
     // pixel r of the lane has X = px0 + COLS r - W/2 (driver.c:131); the planes carry COLS p.x,
     // so the sweep works with X / COLS = Xs0 + r (exact in fp32)
     const float Xs0 = (float)(px0 - A.W / 2) * (1.0f / COLS);
-    unsigned on_image = 0;          // bit r: pixel r of the lane exists
+    unsigned long long on_image = 0;        // bit r: pixel r of the lane exists
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        on_image |= ((px0 + COLS * r < A.W) && (lr < A.rows.rows) ? 1u : 0u) << r;
+        on_image |= ((px0 + COLS * r < A.W) && (lr < A.rows.rows) ? 1ull : 0ull) << r;
 
     // this workgroup's share of the triangle range: chunk blockIdx.y of gridDim.y
     const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
@@ -224,15 +224,16 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
                 const int r_hi = (int)__builtin_floorf(__builtin_fmaxf(hi, -1.0f));
 #if RT_RASTER_CHECK_INTERVAL
                 {
-                    unsigned pass = 0;
+                    unsigned long long pass = 0;
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
                         const float Xs = Xs0 + (float)k;
                         const float u1 = __builtin_fmaf(Xs, cur.P.x, yu);
                         const float w1 = __builtin_fmaf(Xs, cur.Q.x, yw);
-                        pass |= ((unsigned)(__float_as_int(u1) & __float_as_int(w1)) >> 31) << k;
+                        pass |= (unsigned long long)((unsigned)(__float_as_int(u1) & __float_as_int(w1)) >> 31) << k;
                     }
-                    const unsigned inside = r > r_hi ? 0u : ((r_hi >= 31 ? ~0u : (2u << r_hi) - 1u) & ~((1u << r) - 1u));
+                    const unsigned long long inside =
+                        r > r_hi ? 0ull : ((r_hi >= 63 ? ~0ull : (2ull << r_hi) - 1ull) & ~((1ull << r) - 1ull));
                     if ((pass & ~inside) && A.tests) atomicAdd(A.tests, 1ull << 48);
                 }
 #endif
@@ -240,7 +241,7 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
                     const float Xs = Xs0 + (float)r;
                     const float u1 = __builtin_fmaf(Xs, cur.P.x, yu);
                     const float w1 = __builtin_fmaf(Xs, cur.Q.x, yw);
-                    if ((__float_as_int(u1) & __float_as_int(w1)) < 0 && ((on_image >> r) & 1u))
+                    if ((__float_as_int(u1) & __float_as_int(w1)) < 0 && ((on_image >> r) & 1ull))
                         finish_raster(A, slot0 + COLS * r, tri0 + j, cur, base + j, Xs, Y, u1);
                 }
             }
@@ -683,7 +684,7 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
         int fr = 0, fc = 0, fw = 0;
         const int n = sscanf(force, "%d,%d,%d", &fr, &fc, &fw);
         if (n >= 2 && fc >= 1 && fc <= (tiles < 1 ? 1 : tiles) &&
-            (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == 16 || fr == RT_RASTER_RPL) && fr <= RT_RASTER_RPL) {
+            (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == 16 || fr == 32 || fr == 64) && fr <= RT_RASTER_RPL) {
             *pixels_per_lane = fr;
             *chunks = fc;
             *waves_x = (n == 3 && (fw == 1 || fw == 2 || fw == 4)) ? fw : best_layout(fr);
@@ -749,6 +750,9 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
 #endif
 #if RT_RASTER_RPL >= 32
     case 32: return launch(k_sweep_raster<32>, a, grid, st, "raster sweep");
+#endif
+#if RT_RASTER_RPL >= 64
+    case 64: return launch(k_sweep_raster<64>, a, grid, st, "raster sweep");
 #endif
     }
     rt_set_error("raster sweep: unsupported pixels per lane %d", r);

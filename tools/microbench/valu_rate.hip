@@ -69,6 +69,7 @@ KERNEL2(k_pk_mul, "v_pk_mul_f32 %0, %0, %8\n" "v_pk_mul_f32 %1, %1, %8\n" "v_pk_
 // one triangle and 8 rays (no LDS reads, no branch): what the instruction mix alone costs
 KERNEL1(k_raster16, "v_fma_f32 %0, %8, %9, %0\n" "v_fma_f32 %1, %8, %9, %1\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_b32 %4, %2, %3\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_cmp_gt_i32 vcc, 0, %4\n" )
 KERNEL1(k_raster32, "v_fma_f32 %0, %8, %9, %0\n" "v_fma_f32 %1, %8, %9, %1\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_b32 %4, %2, %3\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_cmp_gt_i32 vcc, 0, %4\n" )
+KERNEL1(k_raster64, "v_fma_f32 %0, %8, %9, %0\n" "v_fma_f32 %1, %8, %9, %1\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_b32 %4, %2, %3\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_cmp_gt_i32 vcc, 0, %4\n" )
 KERNEL1(k_apex8, "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %5, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %6, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %7, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %5, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %6, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %7, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %5, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %6, %2, %3, %0\n" "v_max_f32 %4, %5, %6\n" "v_max3_f32 %4, %4, %7, %5\n" "v_max3_f32 %4, %4, %6, %7\n" "v_max3_f32 %4, %4, %5, %6\n" "v_cmp_le_f32 vcc, 0, %4\n" )
 // the any-hit loop if it used the sign tests of the pixel-grid sweep (not adopted: see DESIGN.md)
 KERNEL1(k_apex8_sign, "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_cmp_gt_i32 vcc, 0, %4\n" )
@@ -141,6 +142,7 @@ int main()
     run("add", k_add, out, wgs);
     run_mix("raster16", k_raster16, out, wgs, 51, 16);
     run_mix("raster32", k_raster32, out, wgs, 99, 32);
+    run_mix("raster64", k_raster64, out, wgs, 195, 64);
     run_mix("apex8", k_apex8, out, wgs, 45, 8);
     run_mix("apex8_sign", k_apex8_sign, out, wgs, 41, 8);
     (void)hipFree(out);
