@@ -30,7 +30,7 @@
 //                   RT_RASTER_RPL pixels of one row, RT_RASTER_COLS columns apart; the row part
 //                   Y*p.y + ez*p.z is formed once per lane and triangle, the first pixel costs
 //                   two FMAs and every further one two additions, and one logic instruction per
-//                   pixel combines the sign bits: 99 VALU instructions per 32 pairs.  Every
+//                   pixel combines the sign bits: 195 VALU instructions per 64 pairs.  Every
 //                   (pixel, triangle) pair is still tested individually.
 //
 // Tiles of RT_TILE triangles (4 planes) are double-buffered in LDS by LDS-DMA loads and read
