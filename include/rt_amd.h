@@ -157,9 +157,10 @@ int rt_place_rows(const uint8_t* rgb8, int W, int H, int y0, int y1, uint8_t* sc
 int rt_band(int H, int nranks, int rank, int* y0, int* y1);
 
 /* A row set that interleaves parts: the rows [y0,y1) are cut into blocks of `block` rows and the
- * blocks are dealt to the parts in rounds of `parts`, forwards in even rounds (block
- * round*parts + part) and backwards in odd ones (block round*parts + parts-1-part), so that a
- * cost that grows steadily down the image is shared evenly.  The rows of a part are numbered
+ * blocks are dealt to the parts in rounds of `parts`, forwards (block round*parts + part) or
+ * backwards (block round*parts + parts-1-part) after the Thue-Morse sequence F B B F B F F B ...
+ * (backwards when the round number has an odd number of one bits), so that a cost that grows
+ * down the image, steadily or faster, is shared evenly.  The rows of a part are numbered
  * locally 0 .. rt_rows_count()-1 in ascending image order, and the outputs of the *_part calls
  * are indexed [local_row * W + x_pix].  parts = 1 is the contiguous band.  Interleaving is how
  * the pixel loop of driver.c:126-193 is split over GPUs when the cost per row is uneven (the

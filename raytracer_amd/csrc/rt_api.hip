@@ -536,7 +536,7 @@ static int rows_of_part(const rt_rows* r)
     const int nblocks = (total + r->block - 1) / r->block;
     int rows = 0;
     for (int round = 0; round * r->parts < nblocks; ++round) {
-        const int b = round * r->parts + ((round & 1) ? r->parts - 1 - r->part : r->part);
+        const int b = round * r->parts + (RowMap::backwards(round) ? r->parts - 1 - r->part : r->part);
         if (b >= nblocks) continue;         // only in the last round
         const int left = total - b * r->block;
         rows += left < r->block ? left : r->block;

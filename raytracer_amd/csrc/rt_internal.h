@@ -178,12 +178,19 @@ int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dm
 // local row lr (0 .. rows-1).
 struct RowMap {
     int y0, rows, block, parts, part;
-    // blocks are dealt to the parts in rounds, forwards in even rounds and backwards in odd
-    // ones, so that a cost that grows steadily down the image is shared evenly
+    // blocks are dealt to the parts in rounds, forwards or backwards after the Thue-Morse
+    // sequence (F B B F B F F B ...: backwards when the round number has an odd number of one
+    // bits), so that a cost that grows down the image -- steadily or faster -- is shared evenly
+    static __host__ __device__ bool backwards(int round)
+    {
+        unsigned x = (unsigned)round;
+        x ^= x >> 16; x ^= x >> 8; x ^= x >> 4; x ^= x >> 2; x ^= x >> 1;
+        return x & 1u;
+    }
     __host__ __device__ int image_row(int lr) const
     {
         const int round = lr / block;
-        const int slot = (round & 1) ? parts - 1 - part : part;
+        const int slot = backwards(round) ? parts - 1 - part : part;
         return y0 + (round * parts + slot) * block + lr % block;
     }
 };

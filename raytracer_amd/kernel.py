@@ -103,7 +103,7 @@ def band(H: int, nranks: int, rank: int) -> tuple[int, int]:
 def rows_part(H: int, parts: int = 1, part: int = 0, block: int = 16, y0: int = 0,
               y1: int | None = None) -> RtRows:
     """Row set `part` of `parts` of the rows [y0,y1), interleaved in blocks of `block` rows dealt
-    forwards and backwards in turn (rt_rows in include/rt_amd.h).  parts = 1 is the contiguous band."""
+    forwards or backwards after the Thue-Morse sequence (rt_rows in include/rt_amd.h).  parts = 1 is the contiguous band."""
     return RtRows(y0, H if y1 is None else y1, block, parts, part)
 
 
@@ -118,7 +118,8 @@ def rows_image_rows(r: RtRows) -> np.ndarray:
     n = rows_count(r)
     lr = np.arange(n)
     rnd = lr // r.block
-    slot = np.where(rnd % 2 == 1, r.parts - 1 - r.part, r.part)       # odd rounds are dealt backwards
+    odd_bits = np.array([bin(int(k)).count("1") & 1 for k in rnd], dtype=bool)   # Thue-Morse: F B B F B F F B
+    slot = np.where(odd_bits, r.parts - 1 - r.part, r.part)
     return r.y0 + (rnd * r.parts + slot) * r.block + lr % r.block
 
 

@@ -52,7 +52,7 @@ def assemble_rows(gathered, H: int, world: int):
 
 def part_rows(H: int, world: int, rank: int, block: int = 16):
     """Interleaved row set of `rank`: one block of `block` rows out of every `world`, dealt
-    forwards and backwards in turn (rt_rows in include/rt_amd.h)."""
+    forwards or backwards after the Thue-Morse sequence (rt_rows in include/rt_amd.h)."""
     return kernel.rows_part(H, world, rank, block)
 
 

@@ -29,13 +29,12 @@ def test_parts_partition_the_image(H, parts, block):
     assert max(len(s) for s in seen) - min(len(s) for s in seen) <= block
 
 
-def test_blocks_are_dealt_forwards_then_backwards():
-    # 3 parts, blocks of 2 rows: round 0 deals blocks 0 1 2 to parts 0 1 2, round 1 deals
-    # blocks 3 4 5 to parts 2 1 0, round 2 forwards again
-    got = [list(kernel.rows_image_rows(kernel.rows_part(18, 3, p, 2))) for p in range(3)]
-    assert got[0] == [0, 1, 10, 11, 12, 13]
-    assert got[1] == [2, 3, 8, 9, 14, 15]
-    assert got[2] == [4, 5, 6, 7, 16, 17]
+def test_blocks_are_dealt_after_the_thue_morse_sequence():
+    # 3 parts, blocks of 2 rows: rounds 0 1 2 3 are dealt forwards, backwards, backwards, forwards
+    got = [list(kernel.rows_image_rows(kernel.rows_part(24, 3, p, 2))) for p in range(3)]
+    assert got[0] == [0, 1, 10, 11, 16, 17, 18, 19]
+    assert got[1] == [2, 3, 8, 9, 14, 15, 20, 21]
+    assert got[2] == [4, 5, 6, 7, 12, 13, 22, 23]
     # a last, incomplete round that is dealt backwards gives its blocks to the last parts
     got = [list(kernel.rows_image_rows(kernel.rows_part(9, 3, p, 2))) for p in range(3)]
     assert got == [[0, 1], [2, 3, 8], [4, 5, 6, 7]]
