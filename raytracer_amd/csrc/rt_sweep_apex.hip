@@ -706,8 +706,8 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
         const RasterMix m = rt_raster_mix(r), h = rt_raster_mix(r / 2);
         const double cost = (double)(m.fma + m.add + m.logic + m.compare) / r * swept(r);
         const double cost_half = (double)(h.fma + h.add + h.logic + h.compare) / (r / 2) * swept(r / 2);
-        // ... unless the wider lanes leave too few workgroups for four rounds of the machine
-        const bool enough = rt_raster_tiles(W, rows, r, best_layout(r)) * max_chunks >= 4 * slots;
+        // ... unless the wider lanes leave too few workgroups for eight rounds of the machine
+        const bool enough = rt_raster_tiles(W, rows, r, best_layout(r)) * max_chunks >= 8 * slots;
         if (cost <= cost_half && enough) break;
         r /= 2;
     }
