@@ -81,7 +81,7 @@ constexpr double rt_raster_flop_per_pair(int rpl)
 {
     return (2.0 * rt_raster_mix(rpl).fma + rt_raster_mix(rpl).add) / rpl;
 }
-constexpr double RT_APEX_FLOP_PER_PAIR = 10.0;
+constexpr double RT_APEX_FLOP_PER_PAIR = 9.0;
 
 // per-ray candidate counter written by the sweep: low bits = candidates pushed, plus
 constexpr int RT_CNT_OCCLUDED = 0x40000000;   // any-hit: a certain hit was found

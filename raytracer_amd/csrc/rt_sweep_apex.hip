@@ -14,11 +14,12 @@
 // list; the fp64 pass of rt_exact.hip then decides with the reference's exact arithmetic.
 //
 //   k_sweep_apex    any-hit, for the shadow rays of up to four lights.  Since U + W' = det, the
-//                   slab is U * W' >= 0: per pair  s = fma(U, W', c)  with c the per-triangle
+//                   slab is U * W' >= 0: per pair  U * W' >= -c  with c the per-triangle
 //                   rounding allowance that makes the fp32 test a conservative filter
-//                   (derivation at k_pack_apex), rare path when s >= 0.  Directions are scaled to
+//                   (derivation at k_pack_apex), rare path when it holds.  Directions are scaled to
 //                   a unit dominant component (rays binned by that axis, k_bin_rays), so a dot
-//                   product is two FMAs: 5 FMA + the sign test = 5.6 VALU instructions per pair.
+//                   product is two FMAs: 4 FMA, a multiplication and the comparison = 5.6 VALU instructions
+//                   per pair.
 //                   Triangles in the order of their solid angle at the light, triangle ranges
 //                   with survivor compaction in between, triangle chunks that share a ray's
 //                   state through atomics, an occluder cache in front (host side:
@@ -391,21 +392,25 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
         for (int j = 0; j < RT_TILE; ++j) {
             const Tri2 cur = next;
             next = load_tri2(base + ((j + 1) & (RT_TILE - 1)));
+            // U * W' >= -c, with the product as a plain multiplication (a two-operand
+            // instruction: cheaper to issue and on power than the FMA with c; its one rounding
+            // is far inside the 0.1 % by which c exceeds the bound it stands for)
             float s[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float U = dot_ax<AX>(ray[r].u, ray[r].v, cur.P);
                 const float Wp = dot_ax<AX>(ray[r].u, ray[r].v, cur.Q);
-                s[r] = __builtin_fmaf(U, Wp, cur.P.w);
+                s[r] = U * Wp;
             }
             float mx = s[0];
 #pragma unroll
             for (int r = 1; r < R; ++r) mx = __builtin_fmaxf(mx, s[r]);
-            if (__builtin_expect(mx >= 0.0f, 0)) {
+            const float nc = -cur.P.w;
+            if (__builtin_expect(mx >= nc, 0)) {
                 const float4 Hh = base[j + 2 * RT_TILE], N = base[j + 3 * RT_TILE];
                 unsigned pass = 0;
 #pragma unroll
-                for (int r = 0; r < R; ++r) pass |= (s[r] >= 0.0f ? 1u : 0u) << r;
+                for (int r = 0; r < R; ++r) pass |= (s[r] >= nc ? 1u : 0u) << r;
                 while (pass) {
                     const int rs = __builtin_ctz(pass);
                     pass &= pass - 1;
