@@ -160,7 +160,10 @@ int rt_band(int H, int nranks, int rank, int* y0, int* y1);
  * blocks are dealt to the parts in rounds of `parts`, forwards (block round*parts + part) or
  * backwards (block round*parts + parts-1-part) after the Thue-Morse sequence F B B F B F F B ...
  * (backwards when the round number has an odd number of one bits), so that a cost that grows
- * down the image, steadily or faster, is shared evenly.  The rows of a part are numbered
+ * down the image, steadily or faster, is shared evenly.  The rows left after the last complete
+ * round (fewer than block*parts) are not dealt as whole blocks, which would leave some parts one
+ * block short: they are cut into `parts` runs of nearly equal length (run s starts at row
+ * tail*s/parts of them), and the part takes the run of its slot in that round.  The rows of a part are numbered
  * locally 0 .. rt_rows_count()-1 in ascending image order, and the outputs of the *_part calls
  * are indexed [local_row * W + x_pix].  parts = 1 is the contiguous band.  Interleaving is how
  * the pixel loop of driver.c:126-193 is split over GPUs when the cost per row is uneven (the

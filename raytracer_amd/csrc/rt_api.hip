@@ -532,16 +532,8 @@ static int rows_of_part(const rt_rows* r)
 {
     if (!r || r->block <= 0 || r->parts <= 0 || r->part < 0 || r->part >= r->parts || r->y1 < r->y0)
         return -1;
-    const int total = r->y1 - r->y0;
-    const int nblocks = (total + r->block - 1) / r->block;
-    int rows = 0;
-    for (int round = 0; round * r->parts < nblocks; ++round) {
-        const int b = round * r->parts + (RowMap::backwards(round) ? r->parts - 1 - r->part : r->part);
-        if (b >= nblocks) continue;         // only in the last round
-        const int left = total - b * r->block;
-        rows += left < r->block ? left : r->block;
-    }
-    return rows;
+    if ((long)r->block * r->parts > 0x7fffffffL) return -1;
+    return RowMap::of(r->y0, r->y1 - r->y0, r->block, r->parts, r->part).rows;
 }
 
 extern "C" int rt_rows_count(const rt_rows* r)
@@ -561,7 +553,7 @@ extern "C" int rt_rows_image_row(const rt_rows* r, int local_row)
         rt_set_error("rt_rows_image_row: bad row set or row");
         return RT_E_ARG;
     }
-    return RowMap{r->y0, n, r->block, r->parts, r->part}.image_row(local_row);
+    return RowMap::of(r->y0, r->y1 - r->y0, r->block, r->parts, r->part).image_row(local_row);
 }
 
 static int row_map(const rt_rows* r, int H, RowMap* out)
@@ -571,7 +563,7 @@ static int row_map(const rt_rows* r, int H, RowMap* out)
         rt_set_error("bad row set (need 0 <= y0 <= y1 <= H, block > 0, 0 <= part < parts)");
         return RT_E_ARG;
     }
-    *out = RowMap{r->y0, n, r->block, r->parts, r->part};
+    *out = RowMap::of(r->y0, r->y1 - r->y0, r->block, r->parts, r->part);
     return RT_OK;
 }
 

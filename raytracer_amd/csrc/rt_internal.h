@@ -178,23 +178,37 @@ int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dm
 // local row lr (0 .. rows-1).
 struct RowMap {
     int y0, rows, block, parts, part;
+    int full_rounds, tail;   // complete rounds of `parts` blocks, and the rows left after them
     // blocks are dealt to the parts in rounds, forwards or backwards after the Thue-Morse
     // sequence (F B B F B F F B ...: backwards when the round number has an odd number of one
-    // bits), so that a cost that grows down the image -- steadily or faster -- is shared evenly
+    // bits), so that a cost that grows down the image -- steadily or faster -- is shared evenly;
+    // the rows left after the last complete round are cut into `parts` nearly equal runs, one a
+    // part, instead of whole blocks for some parts and none for the others
     static __host__ __device__ bool backwards(int round)
     {
         unsigned x = (unsigned)round;
         x ^= x >> 16; x ^= x >> 8; x ^= x >> 4; x ^= x >> 2; x ^= x >> 1;
         return x & 1u;
     }
+    __host__ __device__ int slot(int round) const { return backwards(round) ? parts - 1 - part : part; }
+    // first row, within the tail, of the run that slot s takes
+    __host__ __device__ int tail_begin(int s) const { return (int)((long)tail * s / parts); }
     __host__ __device__ int image_row(int lr) const
     {
         const int round = lr / block;
-        const int slot = backwards(round) ? parts - 1 - part : part;
-        return y0 + (round * parts + slot) * block + lr % block;
+        if (round < full_rounds) return y0 + (round * parts + slot(round)) * block + lr % block;
+        return y0 + full_rounds * parts * block + tail_begin(slot(full_rounds)) + (lr - full_rounds * block);
+    }
+    // the map of part `part` of `parts` over `total` rows from y0; rows is filled in
+    static __host__ __device__ RowMap of(int y0, int total, int block, int parts, int part)
+    {
+        RowMap m{y0, 0, block, parts, part, total / (block * parts), total % (block * parts)};
+        const int s = m.slot(m.full_rounds);
+        m.rows = m.full_rounds * block + m.tail_begin(s + 1) - m.tail_begin(s);
+        return m;
     }
 };
-inline RowMap rt_band_rows(int y0, int y1) { return RowMap{y0, y1 - y0, y1 - y0 > 0 ? y1 - y0 : 1, 1, 0}; }
+inline RowMap rt_band_rows(int y0, int y1) { return RowMap::of(y0, y1 - y0, y1 - y0 > 0 ? y1 - y0 : 1, 1, 0); }
 
 // rt_sweep.hip
 struct SweepArgs {

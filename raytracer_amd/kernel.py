@@ -103,7 +103,8 @@ def band(H: int, nranks: int, rank: int) -> tuple[int, int]:
 def rows_part(H: int, parts: int = 1, part: int = 0, block: int = 16, y0: int = 0,
               y1: int | None = None) -> RtRows:
     """Row set `part` of `parts` of the rows [y0,y1), interleaved in blocks of `block` rows dealt
-    forwards or backwards after the Thue-Morse sequence (rt_rows in include/rt_amd.h).  parts = 1 is the contiguous band."""
+    forwards or backwards after the Thue-Morse sequence, the rows after the last complete round
+    shared out evenly (rt_rows in include/rt_amd.h).  parts = 1 is the contiguous band."""
     return RtRows(y0, H if y1 is None else y1, block, parts, part)
 
 
@@ -114,13 +115,21 @@ def rows_count(r: RtRows) -> int:
 
 
 def rows_image_rows(r: RtRows) -> np.ndarray:
-    """Image row of every local row of the set, ascending."""
+    """Image row of every local row of the set, ascending (the rule of rt_rows in
+    include/rt_amd.h, restated in numpy)."""
     n = rows_count(r)
+    total = r.y1 - r.y0
+    full_rounds, tail = divmod(total, r.block * r.parts)
+
+    def slot(rnd):
+        odd_bits = np.array([bin(int(k)).count("1") & 1 for k in np.atleast_1d(rnd)], dtype=bool)   # Thue-Morse: F B B F B F F B
+        return np.where(odd_bits, r.parts - 1 - r.part, r.part)
+
     lr = np.arange(n)
     rnd = lr // r.block
-    odd_bits = np.array([bin(int(k)).count("1") & 1 for k in rnd], dtype=bool)   # Thue-Morse: F B B F B F F B
-    slot = np.where(odd_bits, r.parts - 1 - r.part, r.part)
-    return r.y0 + (rnd * r.parts + slot) * r.block + lr % r.block
+    whole = r.y0 + (rnd * r.parts + slot(rnd)) * r.block + lr % r.block
+    run = r.y0 + full_rounds * r.parts * r.block + tail * int(slot(full_rounds)[0]) // r.parts + (lr - full_rounds * r.block)
+    return np.where(rnd < full_rounds, whole, run)
 
 
 # ------------------------------------------------------------------ batched API

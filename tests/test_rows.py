@@ -25,8 +25,8 @@ def test_parts_partition_the_image(H, parts, block):
     allrows = np.sort(np.concatenate(seen))
     assert np.array_equal(allrows, np.arange(H))
     assert parallel.max_part_rows(H, parts, block) == max(len(s) for s in seen)
-    # no part holds more than one block more than another
-    assert max(len(s) for s in seen) - min(len(s) for s in seen) <= block
+    # the parts differ by one row at most
+    assert max(len(s) for s in seen) - min(len(s) for s in seen) <= 1
 
 
 def test_blocks_are_dealt_after_the_thue_morse_sequence():
@@ -35,9 +35,13 @@ def test_blocks_are_dealt_after_the_thue_morse_sequence():
     assert got[0] == [0, 1, 10, 11, 16, 17, 18, 19]
     assert got[1] == [2, 3, 8, 9, 14, 15, 20, 21]
     assert got[2] == [4, 5, 6, 7, 12, 13, 22, 23]
-    # a last, incomplete round that is dealt backwards gives its blocks to the last parts
+    # the rows after the last complete round are shared out evenly, in that round's direction
     got = [list(kernel.rows_image_rows(kernel.rows_part(9, 3, p, 2))) for p in range(3)]
-    assert got == [[0, 1], [2, 3, 8], [4, 5, 6, 7]]
+    assert got == [[0, 1, 8], [2, 3, 7], [4, 5, 6]]
+    got = [list(kernel.rows_image_rows(kernel.rows_part(11, 3, p, 2))) for p in range(3)]
+    assert got == [[0, 1, 9, 10], [2, 3, 7, 8], [4, 5, 6]]
+    # 4K over 8 parts: 16 complete rounds and 14 of the last 112 rows each
+    assert [kernel.rows_count(kernel.rows_part(2160, 8, p, 16)) for p in range(8)] == [270] * 8
 
 
 def test_sub_range_and_band():
