@@ -1,4 +1,4 @@
-"""Quick timing of the closest-hit sweep on a synthetic soup (development aid)."""
+"""Quick timing of the closest-hit sweep on a synthetic mesh (development aid)."""
 import argparse, math, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,7 @@ ap.add_argument("--h", type=int, default=1080)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--mesh", default="soup")
 a = ap.parse_args()
-mesh = scenes.triangle_soup(a.tris) if a.mesh == "soup" else scenes.torus(a.tris)
+mesh = {"soup": scenes.triangle_soup, "torus": scenes.torus, "sphere": scenes.sphere}[a.mesh](a.tris)
 fr = kernel.driver_frame(0)
 sc = kernel.Scene(mesh)
 sc.transform(kernel.frame_matrix(fr, "obmat"))
