@@ -979,10 +979,11 @@ extern "C" int rt_render_rows(rt_scene* sc, const rt_frame* f, int W, int H, dou
 
 extern "C" int rt_place_rows_part(const uint8_t* rgb8, int W, int H, const rt_rows* rows, uint8_t* screen)
 {
-    RT_ARG(rgb8 && screen, "null pointer");
     RT_ARG(W > 0 && H > 0, "bad image size");
     RowMap rm;
     RT_TRY(row_map(rows, H, &rm));
+    if (rm.rows == 0) return RT_OK;         // a part may be empty (fewer rows than parts)
+    RT_ARG(rgb8 && screen, "null pointer");
     RT_TRY(rt_ensure_init());
     RT_TRY(rt_launch_place_rows(rgb8, W, H, rm, screen, rt_g().stream));
     RT_HIP(hipStreamSynchronize(rt_g().stream));

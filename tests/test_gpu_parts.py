@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("W,H,parts,block,tris", [(320, 200, 3, 16, 20000), (200, 77, 4, 8, 3000),
-                                                  (640, 64, 2, 16, 100000)])
+                                                  (640, 64, 2, 16, 100000), (96, 21, 8, 16, 2000),
+                                                  (96, 5, 8, 16, 2000)])
 def test_parts_equal_whole(W, H, parts, block, tris):
     mesh = scenes.with_materials(scenes.torus(tris))
     fr = kernel.driver_frame(7)

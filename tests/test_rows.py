@@ -9,7 +9,7 @@ from raytracer_amd import _lib, kernel, parallel
 
 
 @pytest.mark.parametrize("H,parts,block", [(2160, 8, 16), (480, 3, 16), (37, 4, 5), (16, 8, 16), (1, 1, 16),
-                                           (100, 7, 1), (2160, 1, 16)])
+                                           (100, 7, 1), (2160, 1, 16), (5, 8, 16), (21, 8, 16), (1080, 8, 16)])
 def test_parts_partition_the_image(H, parts, block):
     seen = []
     for p in range(parts):
