@@ -71,7 +71,7 @@ KERNEL1(k_raster16, "v_fma_f32 %0, %8, %9, %0\n" "v_fma_f32 %1, %8, %9, %1\n" "v
 KERNEL1(k_raster32, "v_fma_f32 %0, %8, %9, %0\n" "v_fma_f32 %1, %8, %9, %1\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_b32 %4, %2, %3\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_cmp_gt_i32 vcc, 0, %4\n" )
 KERNEL1(k_raster64, "v_fma_f32 %0, %8, %9, %0\n" "v_fma_f32 %1, %8, %9, %1\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_b32 %4, %2, %3\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_add_f32 %2, %2, %8\n" "v_add_f32 %3, %3, %9\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_cmp_gt_i32 vcc, 0, %4\n" )
 KERNEL1(k_apex8, "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %5, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %6, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %7, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %5, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %6, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %7, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %5, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %6, %2, %3, %0\n" "v_max_f32 %4, %5, %6\n" "v_max3_f32 %4, %4, %7, %5\n" "v_max3_f32 %4, %4, %6, %7\n" "v_max3_f32 %4, %4, %5, %6\n" "v_cmp_le_f32 vcc, 0, %4\n" )
-// the any-hit loop if it used the sign tests of the pixel-grid sweep (not adopted: see DESIGN.md)
+// the any-hit loop if it used the sign tests of the pixel-grid sweep (not adopted: shadow rays have no fixed sign of the determinant)
 KERNEL1(k_apex8_sign, "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_cmp_gt_i32 vcc, 0, %4\n" )
 template <class K>
 void run_mix(const char* name, K k, float* out, int wgs, int instrs, int pairs)
