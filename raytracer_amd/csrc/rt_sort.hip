@@ -113,7 +113,7 @@ int rt_launch_sort_triangles(rt_scene* sc, const double apex[3], int32_t* order,
 }
 
 // Sorts the ray numbers of every set (ids_in[s * stride ...], counts[s] of them; counts_dev the
-// same numbers on the device) by direction into ids_out.  Sets smaller than min_rays are copied.
+// same numbers on the device) by direction into ids_out; empty sets are skipped.
 int rt_launch_sort_rays(rt_scene* sc, const double* S, const double* E, const int32_t* ids_in,
                         int32_t* ids_out, const int* counts, const int* counts_dev, int sets,
                         long stride, hipStream_t st)
