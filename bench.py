@@ -320,6 +320,10 @@ def main() -> None:
                 # the 46 flop of a general Moller-Trumbore test with its divisions, for reference only:
                 # this kernel does not execute them, so no rate is derived from this figure
                 "flop_per_test_general_mt": F_TEST,
+                # the rate at which a kernel executing those 46 flop per test would sit at half of
+                # the peak, and this launch's rate against it (a rate of tests, not of flops)
+                "tests_per_s_at_half_peak_general_mt": 0.5 * PEAK_FP32_TFLOPS * 1e12 / F_TEST,
+                "tests_per_s_vs_that": tests_per_s_launch / (0.5 * PEAK_FP32_TFLOPS * 1e12 / F_TEST),
                 "sweep_kernel": {"tile_tris": tile.value, "pixels_per_lane": ppl.value,
                                  "triangle_chunks": chunks.value,
                                  "shadow_rays_per_lane": spl.value, "shadow_flop_per_test": f_shadow.value},
