@@ -88,7 +88,11 @@ int rt_scene_create(rt_scene** out);
 int rt_scene_destroy(rt_scene* sc);
 
 /* Geometry upload (host pointers).  Arrays are 1-indexed like obj_reader.h:41-46: length
- * count+1, slot 0 ignored.  Indices are validated against the counts. */
+ * count+1, slot 0 ignored.  Vertex, normal and texture indices must lie in [1, count], material
+ * indices in [-1, num_mats), texture numbers in [-1, num_textures): the setters check what they
+ * can see and rt_render_rows* checks the tables against each other (RT_E_STATE), so that no
+ * kernel reads out of bounds.  A material with a texture needs At/Bt/Ct and texture
+ * coordinates. */
 int rt_scene_set_vertices(rt_scene* sc, int num_v, const double* x, const double* y, const double* z);
 int rt_scene_set_normals(rt_scene* sc, int num_vn, const double* xn, const double* yn, const double* zn);
 int rt_scene_set_texcoords(rt_scene* sc, int num_vt, const double* u, const double* v);
@@ -153,7 +157,7 @@ int rt_render_rows(rt_scene* sc, const rt_frame* f, int W, int H, double tan_hal
  * falls off-screen.  Both pointers device.  The caller zeroes `screen` once per frame. */
 int rt_place_rows(const uint8_t* rgb8, int W, int H, int y0, int y1, uint8_t* screen);
 
-/* Row band of rank r out of n: contiguous, remainder to the last ranks one row each. */
+/* Row band of rank r out of n: contiguous, H / n rows each, the first H % n ranks one more. */
 int rt_band(int H, int nranks, int rank, int* y0, int* y1);
 
 /* A row set that interleaves parts: the rows [y0,y1) are cut into blocks of `block` rows and the

@@ -3,8 +3,8 @@
  * device API (kernel.h:16-17 takes a `Triangle*`).
  *
  * The reference declares them in obj_reader.h:7-39 in terms of SDL_Surface* and the MSVC
- * constant _MAX_FNAME (260 on that platform, 256 in the stub used when the survey measured
- * sizeof(Triangle) = 488).  A drop-in library cannot include SDL, so the same layout is
+ * constant _MAX_FNAME (256 on that platform; 260 is its _MAX_PATH), which gives
+ * sizeof(Triangle) = 488 with 8-byte pointers.  A drop-in library cannot include SDL, so the same layout is
  * spelled out here with an opaque surface pointer and a compile-time name length.  Code
  * built against the reference's own obj_reader.h can pass its arrays straight through as
  * long as RT_REF_MAX_FNAME equals the _MAX_FNAME it was built with; the library reads only
@@ -53,9 +53,15 @@ typedef struct Triangle {                /* obj_reader.h:25-39 */
 
 #ifdef __cplusplus
 }
-static_assert(RT_REF_MAX_FNAME != 256 || sizeof(Triangle) == 488,
-              "layout drifted from the reference's 488-byte Triangle");
-static_assert(offsetof(Triangle, mtl) == 40, "mtl must start at byte 40");
+#define RT_ABI_STATIC_ASSERT(cond, msg) static_assert(cond, msg)
+#else
+#define RT_ABI_STATIC_ASSERT(cond, msg) _Static_assert(cond, msg)
 #endif
+/* checked in C and C++ translation units alike */
+RT_ABI_STATIC_ASSERT(RT_REF_MAX_FNAME != 256 || sizeof(Triangle) == 488,
+                     "layout drifted from the reference's 488-byte Triangle");
+RT_ABI_STATIC_ASSERT(offsetof(Triangle, mtl) == 40, "mtl must start at byte 40");
+RT_ABI_STATIC_ASSERT(RT_REF_MAX_FNAME != 256 || offsetof(Triangle, mtl.Ka) == 304,
+                     "Ka must start at byte 304");
 
 #endif /* RT_REFERENCE_ABI_H */

@@ -173,7 +173,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
     DevBuf* bufs[] = {&sc->ox, &sc->oy, &sc->oz, &sc->ex, &sc->ey, &sc->ez, &sc->nx, &sc->ny, &sc->nz,
                       &sc->tu, &sc->tv, &sc->iA, &sc->iB, &sc->iC, &sc->iAn, &sc->iBn, &sc->iCn,
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts,
-                      &sc->scratch_max, &sc->mat_dev, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi,
+                      &sc->scratch_max, &sc->mat_dev, &sc->ws_partials, &sc->ws_frame, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
                       &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort, &sc->tri_order};
     for (DevBuf* b : bufs) b->release();
@@ -238,20 +238,29 @@ extern "C" int rt_scene_set_triangles(rt_scene* sc, int num_tris, const int* A, 
 {
     RT_ARG(sc && A && B && C, "null vertex index array");
     RT_ARG(num_tris >= 0, "negative triangle count");
-    RT_ARG(in_range(A, num_tris, 0, sc->num_v) && in_range(B, num_tris, 0, sc->num_v) &&
-               in_range(C, num_tris, 0, sc->num_v),
-           "vertex index outside [0,num_v] (set vertices first)");
+    // 1-indexed like obj_reader.h:41-46: slot 0 of every array is never a real entry (it is left
+    // out of the scene's extent, on which the sweeps' rounding bounds rest)
+    RT_ARG(in_range(A, num_tris, 1, sc->num_v) && in_range(B, num_tris, 1, sc->num_v) &&
+               in_range(C, num_tris, 1, sc->num_v),
+           "vertex index outside [1,num_v] (set vertices first)");
     if (An || Bn || Cn) {
         RT_ARG(An && Bn && Cn, "normal index arrays must come together");
-        RT_ARG(in_range(An, num_tris, 0, sc->num_vn) && in_range(Bn, num_tris, 0, sc->num_vn) &&
-                   in_range(Cn, num_tris, 0, sc->num_vn),
-               "normal index outside [0,num_vn] (set normals first)");
+        RT_ARG(in_range(An, num_tris, 1, sc->num_vn) && in_range(Bn, num_tris, 1, sc->num_vn) &&
+                   in_range(Cn, num_tris, 1, sc->num_vn),
+               "normal index outside [1,num_vn] (set normals first)");
     }
     const bool tex = At && Bt && Ct;
     if (tex)
-        RT_ARG(in_range(At, num_tris, 0, sc->num_vt) && in_range(Bt, num_tris, 0, sc->num_vt) &&
-                   in_range(Ct, num_tris, 0, sc->num_vt),
-               "texture index outside [0,num_vt] (set texcoords first)");
+        RT_ARG(in_range(At, num_tris, 1, sc->num_vt) && in_range(Bt, num_tris, 1, sc->num_vt) &&
+                   in_range(Ct, num_tris, 1, sc->num_vt),
+               "texture index outside [1,num_vt] (set texcoords first)");
+    int mtl_max = -1;
+    if (mtl) {
+        for (int i = 0; i < num_tris; ++i) {
+            RT_ARG(mtl[i] >= -1, "material index below -1");
+            mtl_max = mtl[i] > mtl_max ? mtl[i] : mtl_max;
+        }
+    }
     const size_t bytes = sizeof(int) * (size_t)(num_tris > 0 ? num_tris : 1);
     RT_TRY(upload(sc->iA, A, sizeof(int) * (size_t)num_tris));
     RT_TRY(upload(sc->iB, B, sizeof(int) * (size_t)num_tris));
@@ -275,6 +284,7 @@ extern "C" int rt_scene_set_triangles(rt_scene* sc, int num_tris, const int* A, 
         sc->imtl.release();
     }
     (void)bytes;
+    sc->mtl_max = mtl_max;
     sc->num_tris = num_tris;
     sc->num_tris_padded = ((num_tris + RT_TILE - 1) / RT_TILE) * RT_TILE;
     if (sc->num_tris_padded == 0) sc->num_tris_padded = RT_TILE;
@@ -314,9 +324,9 @@ extern "C" int rt_scene_set_triangles_aos(rt_scene* sc, const Triangle* tris, in
     split_aos(tris, num_tris, idx, mtl);
     // texture indices are uninitialised in the reference for faces without vt
     // (obj_reader.c:96-104,145-160): only pass them on when every one is in range.
-    const bool tex = sc->num_vt > 0 && in_range(idx[6].data(), num_tris, 0, sc->num_vt) &&
-                     in_range(idx[7].data(), num_tris, 0, sc->num_vt) &&
-                     in_range(idx[8].data(), num_tris, 0, sc->num_vt);
+    const bool tex = sc->num_vt > 0 && in_range(idx[6].data(), num_tris, 1, sc->num_vt) &&
+                     in_range(idx[7].data(), num_tris, 1, sc->num_vt) &&
+                     in_range(idx[8].data(), num_tris, 1, sc->num_vt);
     int max_m = -1;
     for (int i = 0; i < num_tris; ++i) max_m = mtl[i] > max_m ? mtl[i] : max_m;
     if (max_m >= 0) {
@@ -350,6 +360,7 @@ extern "C" int rt_scene_set_materials(rt_scene* sc, int num_mats, const double* 
     RT_ARG(num_mats >= 0, "negative material count");
     RT_ARG(num_mats == 0 || (Ka && Kd && Ks), "null colour array");
     std::vector<DevMaterial> m((size_t)num_mats);
+    int map_max = -1;
     for (int i = 0; i < num_mats; ++i) {
         for (int k = 0; k < 3; ++k) {
             m[i].Ka[k] = Ka[3 * i + k];
@@ -360,9 +371,14 @@ extern "C" int rt_scene_set_materials(rt_scene* sc, int num_mats, const double* 
         m[i].map_Kd = map_Kd ? map_Kd[i] : -1;
         m[i].map_Ks = map_Ks ? map_Ks[i] : -1;
         m[i].pad = 0;
+        RT_ARG(m[i].map_Ka >= -1 && m[i].map_Kd >= -1 && m[i].map_Ks >= -1, "texture index below -1");
+        const int mm = m[i].map_Ka > m[i].map_Kd ? m[i].map_Ka : m[i].map_Kd;
+        map_max = mm > map_max ? mm : map_max;
+        map_max = m[i].map_Ks > map_max ? m[i].map_Ks : map_max;
     }
     if (num_mats > 0) RT_TRY(upload(sc->mats, m.data(), sizeof(DevMaterial) * (size_t)num_mats));
     sc->num_mats = num_mats;
+    sc->map_max = map_max;
     return RT_OK;
 }
 
@@ -494,8 +510,9 @@ static int timed_sweep(F&& launch, bool shadow, uint64_t tests_if_closest,
     RT_HIP(hipEventElapsedTime(&ms, g.ev0, g.ev1));
     if (shadow) {
         unsigned long long t = 0;
-        RT_HIP(hipMemcpy(&t, dev_tests, sizeof t, hipMemcpyDeviceToHost));
-        RT_HIP(hipMemset(dev_tests, 0, sizeof t));      // the counter restarts for the next range
+        RT_HIP(hipMemcpyAsync(&t, dev_tests, sizeof t, hipMemcpyDeviceToHost, g.stream));
+        RT_HIP(hipMemsetAsync(dev_tests, 0, sizeof t, g.stream));      // the counter restarts for the next range
+        RT_HIP(hipStreamSynchronize(g.stream));
         g.prof.shadow_ms += ms; g.prof.shadow_launches++; g.prof.shadow_tests += t;
     } else {
         g.prof.sweep_ms += ms; g.prof.sweep_launches++; g.prof.sweep_tests += tests_if_closest;
@@ -509,17 +526,31 @@ static int workspaces(rt_scene* sc, size_t slots)
     RT_TRY(sc->ws_list.reserve(sizeof(int32_t) * slots * RT_LIST_K));
     RT_TRY(sc->ws_ovf.reserve(sizeof(int32_t) * slots));
     RT_TRY(sc->ws_counters.reserve(64));
+    RT_TRY(sc->ws_partials.reserve(RT_OVERFLOW_PARTIAL_BYTES));
     return RT_OK;
 }
 
-static int fetch_counters(rt_scene* sc, bool sync_always)
+// Where a generic-ray trace keeps its per-ray state: the scene's grow-only buffers, or the
+// static scratch array.
+struct RayWorkspace {
+    int32_t *cnt, *list, *ovf;
+    int* counters;
+    void* partials;
+};
+static RayWorkspace scene_workspace(rt_scene* sc)
+{
+    return RayWorkspace{sc->ws_cnt.as<int32_t>(), sc->ws_list.as<int32_t>(), sc->ws_ovf.as<int32_t>(),
+                        sc->ws_counters.as<int>(), sc->ws_partials.p};
+}
+
+static int fetch_counters(const int* counters_dev, bool sync_always)
 {
     // counters[0] = overflowed rays, [1] = fp64 candidates evaluated, [2..3] = pair counter,
     // [4] = live rays of a generic-ray launch
     RtGlobal& g = rt_g();
     if (!g.profiling && !sync_always) return RT_OK;
     int c[5] = {0, 0, 0, 0, 0};
-    RT_HIP(hipMemcpyAsync(c, sc->ws_counters.p, sizeof c, hipMemcpyDeviceToHost, g.stream));
+    RT_HIP(hipMemcpyAsync(c, counters_dev, sizeof c, hipMemcpyDeviceToHost, g.stream));
     RT_HIP(hipStreamSynchronize(g.stream));
     g.prof.exact_overflow += (uint64_t)c[0];
     g.prof.exact_candidates += (uint64_t)c[1];
@@ -621,8 +652,8 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     RT_TRY(rt_launch_resolve_primary(es, W, H, tan_half, rows, a.cnt, a.list, chunks, a.chunk_stride,
                                      hit, tuv, sc->ws_ovf.as<int32_t>(), counters, st));
     RT_TRY(rt_launch_overflow_primary(es, W, H, tan_half, rows, sc->ws_ovf.as<int32_t>(), counters,
-                                      hit, tuv, st));
-    RT_TRY(fetch_counters(sc, false));
+                                      hit, tuv, sc->ws_partials.p, st));
+    RT_TRY(fetch_counters(counters, false));
     RT_HIP(hipStreamSynchronize(st));
     return RT_OK;
 }
@@ -743,39 +774,39 @@ static int anyhit_buffers(rt_scene* sc, size_t entries)
 }
 
 // fp64 confirmation of the candidate lists of n rays + the overflow fallback + statistics
-static int resolve_rays(rt_scene* sc, int n, const double* S, const double* E, bool anyhit,
-                        int32_t* hit, double* tuv, double* point, uint8_t* occ)
+static int resolve_rays(rt_scene* sc, const RayWorkspace& ws, int n, const double* S, const double* E,
+                        bool anyhit, int32_t* hit, double* tuv, double* point, uint8_t* occ)
 {
     RtGlobal& g = rt_g();
     const ExactScene es = exact_of(sc);
-    int* counters = sc->ws_counters.as<int>();
-    RT_TRY(rt_launch_resolve_rays(es, n, S, E, sc->ws_cnt.as<int32_t>(), sc->ws_list.as<int32_t>(),
-                                  anyhit, hit, tuv, point, occ, sc->ws_ovf.as<int32_t>(), counters,
-                                  g.stream));
-    RT_TRY(rt_launch_overflow_rays(es, S, E, sc->ws_ovf.as<int32_t>(), counters, anyhit, hit, tuv,
-                                   point, occ, g.stream));
+    RT_TRY(rt_launch_resolve_rays(es, n, S, E, ws.cnt, ws.list, anyhit, hit, tuv, point, occ, ws.ovf,
+                                  ws.counters, g.stream));
+    RT_TRY(rt_launch_overflow_rays(es, S, E, ws.ovf, ws.counters, anyhit, hit, tuv, point, occ,
+                                   ws.partials, g.stream));
     const uint64_t before = g.prof.rays_live;
-    RT_TRY(fetch_counters(sc, false));
+    RT_TRY(fetch_counters(ws.counters, false));
     if (anyhit) g.prof.rays_shadow += g.prof.rays_live - before;
     else g.prof.rays_primary += g.prof.rays_live - before;
     return RT_OK;
 }
 
 // Rays in general position (rt_sweep.hip).
-static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E, bool anyhit,
-                           int32_t* hit, double* tuv, double* point, uint8_t* occ)
+static int trace_rays_impl(rt_scene* sc, const RayWorkspace* static_ws, int n, const double* S,
+                           const double* E, bool anyhit, int32_t* hit, double* tuv, double* point,
+                           uint8_t* occ)
 {
     hipStream_t st = rt_g().stream;
     if (n == 0) return RT_OK;
-    RT_TRY(workspaces(sc, (size_t)n));
-    RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
+    if (!static_ws) RT_TRY(workspaces(sc, (size_t)n));
+    const RayWorkspace ws = static_ws ? *static_ws : scene_workspace(sc);
+    RT_HIP(hipMemsetAsync(ws.counters, 0, 64, st));
     SweepArgs a{};
     a.planes = sc->planes.as<float4>(); a.plane_stride = sc->num_tris_padded;
     a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
     a.scene_radius = sc->radius;
     a.n_rays = n; a.S = S; a.E = E;
-    a.cnt = sc->ws_cnt.as<int32_t>(); a.list = sc->ws_list.as<int32_t>();
-    a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
+    a.cnt = ws.cnt; a.list = ws.list;
+    a.tests = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws.counters) + 8);
     const int np = sc->num_tris_padded;
     if (!anyhit) {
         a.tri_begin = 0; a.tri_end = np;
@@ -783,11 +814,15 @@ static int trace_rays_impl(rt_scene* sc, int n, const double* S, const double* E
         RT_TRY(timed_sweep([&] { return rt_launch_sweep_rays(a, false, st); }, false,
                            wgs * RT_RAYS_PER_WG * (uint64_t)np, a.tests));
     } else {
+        if (static_ws) {
+            rt_set_error("any-hit sweeps have no static workspace");
+            return RT_E_ARG;
+        }
         RT_TRY(anyhit_buffers(sc, (size_t)n));
         RT_TRY(anyhit_ranges(sc, a, n, 1, n, false,
                              [&](const SweepArgs& r) { return rt_launch_sweep_rays(r, true, st); }));
     }
-    return resolve_rays(sc, n, S, E, anyhit, hit, tuv, point, occ);
+    return resolve_rays(sc, ws, n, S, E, anyhit, hit, tuv, point, occ);
 }
 
 // Shadow rays of the pixel loop: [light][pixel] rays that end at their light (k_shadow_setup).
@@ -869,7 +904,7 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
             RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
         }
     }
-    return resolve_rays(sc, (int)(npix * (size_t)L), S, E, true, nullptr, nullptr, nullptr, occ);
+    return resolve_rays(sc, scene_workspace(sc), (int)(npix * (size_t)L), S, E, true, nullptr, nullptr, nullptr, occ);
 }
 
 extern "C" int rt_trace_rays(rt_scene* sc, int n, const double* S, const double* E, int32_t* hit,
@@ -878,7 +913,7 @@ extern "C" int rt_trace_rays(rt_scene* sc, int n, const double* S, const double*
     RT_TRY(require_ready(sc));
     RT_ARG(n >= 0, "negative ray count");
     RT_ARG(n == 0 || (S && E && hit), "null pointer");
-    RT_TRY(trace_rays_impl(sc, n, S, E, false, hit, tuv, point, nullptr));
+    RT_TRY(trace_rays_impl(sc, nullptr, n, S, E, false, hit, tuv, point, nullptr));
     RT_HIP(hipStreamSynchronize(rt_g().stream));
     return RT_OK;
 }
@@ -888,7 +923,7 @@ extern "C" int rt_occluded(rt_scene* sc, int n, const double* S, const double* E
     RT_TRY(require_ready(sc));
     RT_ARG(n >= 0, "negative ray count");
     RT_ARG(n == 0 || (S && E && occ), "null pointer");
-    RT_TRY(trace_rays_impl(sc, n, S, E, true, nullptr, nullptr, nullptr, occ));
+    RT_TRY(trace_rays_impl(sc, nullptr, n, S, E, true, nullptr, nullptr, nullptr, occ));
     RT_HIP(hipStreamSynchronize(rt_g().stream));
     return RT_OK;
 }
@@ -907,7 +942,7 @@ static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, doubl
     RT_TRY(trace_primary_rows(sc, W, H, tan_half, rows, hit, tuv));
 
     // frame constants
-    static DevBuf frame_dev;
+    DevBuf& frame_dev = sc->ws_frame;
     RT_TRY(frame_dev.reserve(sizeof(DevFrame)));
     static DevFrame hf;     // static: outlives the async copy below
     hf.num_lights = L;
@@ -962,6 +997,21 @@ extern "C" int rt_render_rows_part(rt_scene* sc, const rt_frame* f, int W, int H
     RT_ARG(W > 0 && H > 0, "bad image size");
     RT_ARG(tan_half > 0, "tan_half must be positive");
     RT_ARG(sc->iAn.p && sc->nx.p, "scene has no normals (needed for shading)");
+    // the shading kernel indexes these tables without checks of its own
+    if (sc->mtl_max >= sc->num_mats) {
+        rt_set_error("a triangle uses material %d but only %d are set", sc->mtl_max, sc->num_mats);
+        return RT_E_STATE;
+    }
+    if (sc->mtl_max >= 0 && sc->map_max >= 0) {
+        if (sc->map_max >= sc->num_tex) {
+            rt_set_error("a material uses texture %d but only %d are set", sc->map_max, sc->num_tex);
+            return RT_E_STATE;
+        }
+        if (!sc->has_tex_idx || !sc->tu.p || !sc->tv.p) {
+            rt_set_error("a textured material needs texture coordinates and At/Bt/Ct on every triangle");
+            return RT_E_STATE;
+        }
+    }
     RowMap rm;
     RT_TRY(row_map(rows, H, &rm));
     if (rm.rows == 0) return RT_OK;

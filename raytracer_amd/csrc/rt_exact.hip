@@ -521,44 +521,44 @@ int rt_launch_resolve_rays(const ExactScene& es, int n, const double* S, const d
     return launched("resolve_rays");
 }
 
-static DevBuf& overflow_partials()
-{
-    static DevBuf b;        // OVERFLOW_GRID partial winners, kept for the life of the process
-    return b;
-}
+static_assert(sizeof(Partial) * OVERFLOW_GRID == RT_OVERFLOW_PARTIAL_BYTES, "partial-winner buffer size");
 
 template <class RAYS, bool ANYHIT>
 static int launch_overflow(const ExactScene& es, const RAYS& rays, const int32_t* ovf, const int* counters,
-                           int32_t* hit, double* tuv, double* point, uint8_t* occ, hipStream_t st)
+                           int32_t* hit, double* tuv, double* point, uint8_t* occ, void* partials,
+                           hipStream_t st)
 {
-    DevBuf& pb = overflow_partials();
-    int rc = pb.reserve(sizeof(Partial) * OVERFLOW_GRID);
-    if (rc) return rc;
+    Partial* part = static_cast<Partial*>(partials);
+    if (!part) {
+        rt_set_error("overflow: no buffer for the partial winners");
+        return RT_E_ARG;
+    }
+    int rc;
     hipLaunchKernelGGL((k_overflow<RAYS, ANYHIT>), dim3(OVERFLOW_GRID), dim3(RT_WG), 0, st, es, rays, ovf,
-                       counters, pb.as<Partial>(), hit, tuv, point, occ);
+                       counters, part, hit, tuv, point, occ);
     rc = launched("overflow");
     if (rc) return rc;
     // merges at most OVERFLOW_GRID / 2 rays (more rays than that take the direct path)
     hipLaunchKernelGGL((k_overflow_merge<RAYS, ANYHIT>), dim3(OVERFLOW_GRID / 2 / RT_WG), dim3(RT_WG), 0, st,
-                       rays, ovf, counters, pb.as<Partial>(), hit, tuv, point, occ);
+                       rays, ovf, counters, part, hit, tuv, point, occ);
     return launched("overflow_merge");
 }
 
 int rt_launch_overflow_primary(const ExactScene& es, int W, int H, double tan_half, const RowMap& rows,
                                const int32_t* ovf, const int* counters, int32_t* hit, double* tuv,
-                               hipStream_t st)
+                               void* partials, hipStream_t st)
 {
     const PrimaryRays rays{W, H, tan_half, rows};
-    return launch_overflow<PrimaryRays, false>(es, rays, ovf, counters, hit, tuv, nullptr, nullptr, st);
+    return launch_overflow<PrimaryRays, false>(es, rays, ovf, counters, hit, tuv, nullptr, nullptr, partials, st);
 }
 
 int rt_launch_overflow_rays(const ExactScene& es, const double* S, const double* E,
                             const int32_t* ovf, const int* counters, bool anyhit, int32_t* hit,
-                            double* tuv, double* point, uint8_t* occ, hipStream_t st)
+                            double* tuv, double* point, uint8_t* occ, void* partials, hipStream_t st)
 {
     const ListedRays rays{S, E};
-    return anyhit ? launch_overflow<ListedRays, true>(es, rays, ovf, counters, hit, tuv, point, occ, st)
-                  : launch_overflow<ListedRays, false>(es, rays, ovf, counters, hit, tuv, point, occ, st);
+    return anyhit ? launch_overflow<ListedRays, true>(es, rays, ovf, counters, hit, tuv, point, occ, partials, st)
+                  : launch_overflow<ListedRays, false>(es, rays, ovf, counters, hit, tuv, point, occ, partials, st);
 }
 
 int rt_launch_try_cached(const ExactScene& es, const double* S, const double* E, const int32_t* lists,

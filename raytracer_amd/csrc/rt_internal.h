@@ -114,6 +114,9 @@ struct rt_scene {
     DevBuf tex_desc;            // DevTexture[num_tex]
     std::vector<DevBuf> tex_data;
     bool has_tex_idx = false;
+    // host-side extremes of the index arrays, checked against the tables before a render
+    int mtl_max = -1;           // largest mtl[] entry
+    int map_max = -1;           // largest map_Ka/Kd/Ks entry of any material (-1: no textured material)
 
     // fp32 sweep buffer: RT_PLANES float4 planes of num_tris_padded entries each, back to back
     // (contents per formulation: k_pack in rt_transform.hip)
@@ -125,7 +128,7 @@ struct rt_scene {
     DevBuf mat_dev;             // the 4x4 of the current transform
 
     // per-call workspaces (grow-only)
-    DevBuf ws_cnt, ws_list, ws_ovf, ws_counters, ws_besthi;
+    DevBuf ws_cnt, ws_list, ws_ovf, ws_counters, ws_besthi, ws_partials, ws_frame;
     DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_act2, ws_live, ws_occid, ws_sort;
 };
 
@@ -319,13 +322,16 @@ int rt_launch_resolve_rays(const ExactScene& es, int n, const double* S, const d
                            const int32_t* cnt, const int32_t* list, bool anyhit,
                            int32_t* hit, double* tuv, double* point, uint8_t* occ,
                            int32_t* ovf, int* counters, hipStream_t st);
+// `partials`: RT_OVERFLOW_PARTIAL_BYTES of device memory for the partial winners of rays whose
+// sweep is cut into mesh slices
+constexpr size_t RT_OVERFLOW_PARTIAL_BYTES = 32 * 2048;
 int rt_launch_overflow_primary(const ExactScene& es, int W, int H, double tan_half, const RowMap& rows,
                                const int32_t* ovf, const int* counters,
-                               int32_t* hit, double* tuv, hipStream_t st);
+                               int32_t* hit, double* tuv, void* partials, hipStream_t st);
 int rt_launch_overflow_rays(const ExactScene& es, const double* S, const double* E,
                             const int32_t* ovf, const int* counters, bool anyhit,
                             int32_t* hit, double* tuv, double* point, uint8_t* occ,
-                            hipStream_t st);
+                            void* partials, hipStream_t st);
 // Occluder cache: every listed ray (sets = lights x 3, laid out like the apex sweep's lists)
 // tries the triangles that occluded the sample rays around its pixel with the exact test and
 // is marked occluded in cnt[] on success.

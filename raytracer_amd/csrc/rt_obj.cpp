@@ -527,12 +527,16 @@ extern "C" int rt_scene_set_obj(rt_scene* sc, const rt_obj* o)
         rc = rt_scene_set_textures(sc, (int)w.size(), w.data(), h.data(), px.data());
         if (rc) return rc;
     }
-    rc = rt_scene_set_materials(sc, v.num_mats, v.Ka, v.Kd, v.Ks, v.map_Ka, v.map_Kd, v.map_Ks);
-    if (rc) return rc;
     const bool tex = v.num_vt > 0;
     bool tex_ok = tex;
     for (int i = 0; tex_ok && i < v.num_tris; ++i)
         tex_ok = v.At[i] >= 1 && v.Bt[i] >= 1 && v.Ct[i] >= 1;
+    // Faces without vt leave At/Bt/Ct uninitialised in the reference (obj_reader.c:96-104,145-160)
+    // and its texture lookup then reads through them, which is undefined; here a mesh with any
+    // such face is shaded with its materials' constant colours, like a failed IMG_Load.
+    rc = rt_scene_set_materials(sc, v.num_mats, v.Ka, v.Kd, v.Ks, tex_ok ? v.map_Ka : nullptr,
+                                tex_ok ? v.map_Kd : nullptr, tex_ok ? v.map_Ks : nullptr);
+    if (rc) return rc;
     return rt_scene_set_triangles(sc, v.num_tris, v.A, v.B, v.C, v.An, v.Bn, v.Cn,
                                   tex_ok ? v.At : nullptr, tex_ok ? v.Bt : nullptr,
                                   tex_ok ? v.Ct : nullptr, v.mtl);

@@ -225,6 +225,77 @@ def test_error_codes_instead_of_faults():
     sc.close()
 
 
+def test_inconsistent_material_tables_are_errors_not_faults(tmp_path):
+    """Index tables that do not fit each other never reach the shading kernel: material and
+    texture numbers out of range and textured materials on triangles without texture indices
+    are refused with a status code."""
+    lib = _lib.load()
+    fr = kernel.driver_frame(0)
+    hit = torch.empty(64 * 48, dtype=torch.int32, device="cuda")
+
+    def render(sc):
+        return lib.rt_render_rows(sc.h, C.byref(fr), 64, 48, TAN_HALF, 0, 48, hit.data_ptr(), None, None, None)
+
+    # 1. a textured material, triangles without At/Bt/Ct
+    mesh = scenes.with_materials(scenes.torus(200), num_mats=2)
+    mesh.textures = [np.full((4, 4, 3), 200, np.uint8)]
+    mesh.map_Kd = np.array([0, -1], np.int32)
+    sc = kernel.Scene(mesh)
+    sc.transform(kernel.frame_matrix(fr, "obmat"))
+    assert render(sc) == -3 and b"texture coordinates" in lib.rt_last_error()
+    sc.close()
+    # 2. a texture number beyond the textures that were set
+    mesh = scenes.with_materials(scenes.torus(200, with_uv=True), num_mats=2)
+    mesh.textures = [np.full((4, 4, 3), 200, np.uint8)]
+    mesh.map_Ks = np.array([-1, 1], np.int32)
+    sc = kernel.Scene(mesh)
+    sc.transform(kernel.frame_matrix(fr, "obmat"))
+    assert render(sc) == -3 and b"texture 1" in lib.rt_last_error()
+    sc.close()
+    # 3. a material index beyond the material table; below -1; vertex slot 0
+    mesh = scenes.with_materials(scenes.torus(200), num_mats=2)
+    mesh.mtl = mesh.mtl.copy()
+    mesh.mtl[7] = 2
+    sc = kernel.Scene(mesh)
+    sc.transform(kernel.frame_matrix(fr, "obmat"))
+    assert render(sc) == -3 and b"material 2" in lib.rt_last_error()
+    ip = lambda a: a.ctypes.data_as(_lib.c_int_p)
+    low = mesh.mtl.copy()
+    low[0] = -2
+    args = [ip(mesh.A), ip(mesh.B), ip(mesh.C), ip(mesh.An), ip(mesh.Bn), ip(mesh.Cn), None, None, None]
+    assert lib.rt_scene_set_triangles(sc.h, mesh.num_tris, *args, ip(low)) == -1
+    zero = mesh.B.copy()
+    zero[5] = 0
+    args[1] = ip(zero)
+    assert lib.rt_scene_set_triangles(sc.h, mesh.num_tris, *args, ip(mesh.mtl)) == -1
+    assert b"[1,num_v]" in lib.rt_last_error()
+    sc.close()
+    # 4. the loader: a material with map_Kd on faces without vt (v//vn) is shaded with the
+    #    material's constant colours, like a texture that failed to load
+    ppm = tmp_path / "t.ppm"
+    ppm.write_bytes(b"P6\n2 2\n255\n" + bytes([255, 0, 0] * 4))
+    images = []
+    for name, map_line in (("with_map", "map_Kd t.ppm\nmap_Ka t.ppm\n"), ("without", "")):
+        (tmp_path / f"{name}.mtl").write_text(
+            "newmtl red\nKa 0.3 0.3 0.3\nKd 0.2 0.9 0.4\nKs 0.5 0.5 0.5\n" + map_line)
+        (tmp_path / f"{name}.obj").write_text(
+            f"mtllib {name}.mtl\nv -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nvn 0 0 1\nusemtl red\n"
+            "f 1//1 2//1 3//1 4//1\n")
+        h = C.c_void_p()
+        _lib.check(lib.rt_obj_load(str(tmp_path / f"{name}.obj").encode(), C.byref(h)), "rt_obj_load")
+        sc = kernel.Scene()
+        _lib.check(lib.rt_scene_set_obj(sc.h, h), "rt_scene_set_obj")
+        sc.transform(kernel.frame_matrix(fr, "obmat"))
+        argb = torch.empty((48, 64, 3), dtype=torch.float64, device="cuda")
+        _lib.check(lib.rt_render_rows(sc.h, C.byref(fr), 64, 48, TAN_HALF, 0, 48, hit.data_ptr(), None,
+                                      argb.data_ptr(), None), "rt_render_rows")
+        assert int((hit.view(48, 64) >= 0).sum()) > 100
+        images.append(argb)
+        lib.rt_obj_free(h)
+        sc.close()
+    assert torch.equal(images[0], images[1])
+
+
 @pytest.mark.parametrize("dist", [300.0, 3.0e5])
 def test_far_ray_origins(dist):
     """The general-position sweep works with the ray's moment (a property of its line), so the

@@ -126,8 +126,8 @@ def test_config3_bunny_class_4k():
 
 def test_config4_soup_1m_4k_rows():
     """Config 4 geometry (1M-triangle soup, 3840x2160): two full rows against the oracle and
-    band/determinism properties on a 128-row band (a full 4K primary sweep of 1M triangles
-    takes ~3.5 s and is exercised by bench.py)."""
+    band/determinism properties on a 128-row band (primary rays only; the shaded path is
+    test_config4_soup_1m_4k_shaded_band)."""
     mesh = scenes.triangle_soup(1_000_000, seed=12345)
     fr = kernel.driver_frame(0)
     obmat = kernel.frame_matrix(fr, "obmat")
@@ -149,6 +149,67 @@ def test_config4_soup_1m_4k_rows():
         m = ref["hit"][y] >= 0
         assert np.array_equal(tuv_t.cpu().numpy()[y - y0][m], ref["tuv"][y][m])
     sc.close()
+
+
+def _shaded_rows_vs_oracle(mesh, frame_no, W, H, band, check_rows, min_shadow_launches):
+    """The whole pixel loop on a band tall enough that the shadow phase takes its production
+    route by itself (default thresholds): occluder cache, rays sorted by direction, triangle
+    ranges with survivor compaction.  Full rows of the band against the oracle's shaded rows."""
+    fr = kernel.driver_frame(frame_no)
+    obmat = kernel.frame_matrix(fr, "obmat")
+    sc = kernel.Scene(mesh)
+    sc.transform(obmat)
+    y0, y1 = band
+    kernel.profile_enable(True)
+    kernel.profile_reset()
+    out = sc.render_rows(fr, W, H, TAN_HALF, y0, y1)
+    prof = kernel.profile_get()
+    kernel.profile_enable(False)
+    # several any-hit launches per cache level = the ranged branch ran (a small sweep is one launch)
+    assert prof.shadow_launches >= min_shadow_launches, prof.shadow_launches
+    assert prof.rays_shadow > 0 and prof.shadow_tests > 0
+    # the same band again without the profiling syncs in between: identical
+    again = sc.render_rows(fr, W, H, TAN_HALF, y0, y1, want=("hit", "rgb8"))
+    assert torch.equal(again["hit"], out["hit"]) and torch.equal(again["rgb8"], out["rgb8"])
+    hit, tuv = out["hit"].cpu().numpy(), out["tuv"].cpu().numpy()
+    argb, rgb8 = out["argb"].cpu().numpy(), out["rgb8"].cpu().numpy()
+    X, Y, Z = O.transform(mesh, obmat)
+    osc = O.Scene(mesh, X, Y, Z)
+    shadowed = lit = 0
+    for y in check_rows:
+        ref = O.render_rows(osc, O.frame_from(fr), W, H, TAN_HALF, y0=y, y1=y + 1, shade=True)
+        k = y - y0
+        assert np.array_equal(hit[k], ref["hit"][y]), f"row {y}: hit index differs from the oracle"
+        m = ref["hit"][y] >= 0
+        assert m.sum() > 0.02 * W
+        assert np.array_equal(tuv[k][m], ref["tuv"][y][m])
+        assert np.abs(argb[k] - ref["argb"][y]).max() < 1e-9          # libm pow vs the device's
+        assert np.abs(rgb8[k].astype(int) - ref["rgb8"][y].astype(int)).max() <= 1   # 1/255 per channel
+        assert ref["shadow_rays"] > 0
+        # pixels no light reaches (occluded, facing away or out of range) show only the ambient
+        # term (light_model.c:133-139 with K = 1); the rows must hold both kinds
+        only_ambient = np.abs(ref["argb"][y][m] - 0.2).max(axis=1) < 1e-12
+        shadowed += int(only_ambient.sum())
+        lit += int((~only_ambient).sum())
+    assert shadowed > 0 and lit > 0
+    sc.close()
+
+
+def test_config4_soup_1m_4k_shaded_band():
+    """Config 4 through the whole pixel loop at production scale: 1 M triangles, 3840 wide, a
+    64-row band (2.5e11 primary pairs; 3e4 + 4e5 shadow rays x 1 M triangles, far above the
+    1.5e10-pair threshold of the ranged sweeps), two full rows against the oracle
+    (light_model.c:60-76: each hit pixel's shadow rays against every triangle)."""
+    _shaded_rows_vs_oracle(scenes.triangle_soup(1_000_000, seed=12345), 0, 3840, 2160,
+                           band=(1000, 1064), check_rows=(1003, 1050), min_shadow_launches=8)
+
+
+def test_config3_bunny_class_4k_shaded_frame():
+    """Config 3 through the whole pixel loop: the full 3840x2160 frame of the 69 451-triangle
+    mesh (its shadow rays x triangles cross the ranged sweeps' threshold), six full rows against
+    the oracle."""
+    _shaded_rows_vs_oracle(scenes.torus(69451), 7, 3840, 2160, band=(0, 2160),
+                           check_rows=(200, 700, 1000, 1081, 1400, 1900), min_shadow_launches=5)
 
 
 def test_config5_rotation_sequence_frames():
