@@ -102,6 +102,7 @@ SIGNATURES = {
     "rt_trace_primary": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5),
+    "rt_trace_rays_static": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5),
     "rt_occluded": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 3),
     "rt_render_rows": (C.c_int, [C.c_void_p, C.POINTER(RtFrame), C.c_int, C.c_int, C.c_double,
                                  C.c_int, C.c_int] + [C.c_void_p] * 4),

@@ -25,6 +25,26 @@ RtGlobal& rt_g()
     return g;
 }
 
+// ---------------------------------------------------------------- static scratch
+// Workspace of rt_trace_rays_static, the entry point that allocates nothing: per-ray candidate
+// counts and lists, the overflow queue, the counters and the partial winners of overflowed rays,
+// for at most RT_STATIC_MAX_RAYS rays.  Every GPU the library runs on holds its own copy of the
+// array at its own address until the process ends; the name below is only the host-side handle
+// of the symbol, the address kernels are given comes from hipGetSymbolAddress (rt_init).
+namespace {
+constexpr size_t kStaticAlign = 256;
+constexpr size_t static_round(size_t b) { return (b + kStaticAlign - 1) / kStaticAlign * kStaticAlign; }
+constexpr size_t kStaticOffCounters = 0;
+constexpr size_t kStaticOffCnt = static_round(64);
+constexpr size_t kStaticOffList = kStaticOffCnt + static_round(sizeof(int32_t) * RT_STATIC_MAX_RAYS);
+constexpr size_t kStaticOffOvf = kStaticOffList + static_round(sizeof(int32_t) * RT_LIST_K * (size_t)RT_STATIC_MAX_RAYS);
+constexpr size_t kStaticOffPartials = kStaticOffOvf + static_round(sizeof(int32_t) * RT_STATIC_MAX_RAYS);
+constexpr size_t kStaticBytes = kStaticOffPartials + static_round(RT_OVERFLOW_PARTIAL_BYTES);
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};     // device address of `scratch`, per device ordinal
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
 extern "C" int rt_device_count(void)
 {
     int n = 0;
@@ -55,6 +75,12 @@ extern "C" int rt_init(int device_ordinal)
     if (!g.ev0) {
         RT_HIP(hipEventCreate(&g.ev0));
         RT_HIP(hipEventCreate(&g.ev1));
+    }
+    if (device_ordinal < kMaxDevices && !g_scratch_ptr[device_ordinal]) {
+        // this device's copy of the static scratch array (the device is current here)
+        unsigned char* ptr = nullptr;
+        RT_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[device_ordinal] = ptr;
     }
     g.device = device_ordinal;
     g.inited = true;
@@ -915,6 +941,39 @@ extern "C" int rt_trace_rays(rt_scene* sc, int n, const double* S, const double*
     RT_ARG(n == 0 || (S && E && hit), "null pointer");
     RT_TRY(trace_rays_impl(sc, nullptr, n, S, E, false, hit, tuv, point, nullptr));
     RT_HIP(hipStreamSynchronize(rt_g().stream));
+    return RT_OK;
+}
+
+// rt_trace_rays on the static scratch array: no hipMalloc / hipFree, no grow-only buffer, no
+// profiling read-backs.  The scene's own buffers (geometry, planes) were allocated when it was
+// set up and are only read here.
+extern "C" int rt_trace_rays_static(rt_scene* sc, int n, const double* S, const double* E, int32_t* hit,
+                                    double* tuv, double* point)
+{
+    RT_TRY(require_ready(sc));
+    RT_ARG(n >= 0, "negative ray count");
+    RT_ARG(n == 0 || (S && E && hit), "null pointer");
+    if (n > RT_STATIC_MAX_RAYS) {
+        rt_set_error("rt_trace_rays_static: %d rays exceed the static workspace's %d; split the batch or "
+                     "use rt_trace_rays", n, RT_STATIC_MAX_RAYS);
+        return RT_E_LIMIT;
+    }
+    RtGlobal& g = rt_g();
+    unsigned char* base = g.device >= 0 && g.device < kMaxDevices ? g_scratch_ptr[g.device] : nullptr;
+    if (!base) {
+        rt_set_error("rt_trace_rays_static: no static workspace on device %d (rt_init not run on it)", g.device);
+        return RT_E_STATE;
+    }
+    const RayWorkspace ws{reinterpret_cast<int32_t*>(base + kStaticOffCnt),
+                          reinterpret_cast<int32_t*>(base + kStaticOffList),
+                          reinterpret_cast<int32_t*>(base + kStaticOffOvf),
+                          reinterpret_cast<int*>(base + kStaticOffCounters), base + kStaticOffPartials};
+    const bool was_profiling = g.profiling;
+    g.profiling = false;            // the profiling path reads counters back through staging copies
+    const int rc = trace_rays_impl(sc, &ws, n, S, E, false, hit, tuv, point, nullptr);
+    g.profiling = was_profiling;
+    RT_TRY(rc);
+    RT_HIP(hipStreamSynchronize(g.stream));
     return RT_OK;
 }
 

@@ -219,8 +219,9 @@ class Scene:
                                         tuv.data_ptr()), "rt_trace_primary")
         return hit, tuv
 
-    def trace_rays(self, S, E):
-        """S, E: [n,3] float64 (numpy or device tensors).  Returns hit, tuv, point tensors."""
+    def trace_rays(self, S, E, static: bool = False):
+        """S, E: [n,3] float64 (numpy or device tensors).  Returns hit, tuv, point tensors.
+        static=True goes through rt_trace_rays_static (the library allocates nothing)."""
         t = self.torch
         S = t.as_tensor(S, dtype=t.float64, device=self.device).contiguous()
         E = t.as_tensor(E, dtype=t.float64, device=self.device).contiguous()
@@ -228,8 +229,9 @@ class Scene:
         hit = self._empty((n,), t.int32)
         tuv = t.zeros((n, 3), dtype=t.float64, device=self.device)
         point = t.zeros((n, 3), dtype=t.float64, device=self.device)
-        check(self.lib.rt_trace_rays(self.h, n, S.data_ptr(), E.data_ptr(), hit.data_ptr(),
-                                     tuv.data_ptr(), point.data_ptr()), "rt_trace_rays")
+        fn = self.lib.rt_trace_rays_static if static else self.lib.rt_trace_rays
+        check(fn(self.h, n, S.data_ptr(), E.data_ptr(), hit.data_ptr(), tuv.data_ptr(), point.data_ptr()),
+              "rt_trace_rays_static" if static else "rt_trace_rays")
         return hit, tuv, point
 
     def occluded(self, S, E):
