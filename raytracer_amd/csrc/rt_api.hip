@@ -632,13 +632,14 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     const size_t npix = (size_t)W * rows.rows;
     int rpl = 1, chunks = 1, waves_x = 4;
     rt_raster_shape(W, rows.rows, sc->num_tris_padded / RT_TILE, &rpl, &chunks, &waves_x);
-    const size_t slots = npix * (size_t)chunks;
-    RT_TRY(workspaces(sc, slots));
-    RT_TRY(sc->ws_besthi.reserve(sizeof(float) * slots));
+    // per pixel: a count, a bound and RT_RASTER_LIST_K list slots, shared by all triangle chunks
+    static_assert(RT_RASTER_LIST_K % RT_LIST_K == 0, "the pixel lists are carved out of the ray lists' buffer");
+    RT_TRY(workspaces(sc, npix * (size_t)(RT_RASTER_LIST_K / RT_LIST_K)));
+    RT_TRY(sc->ws_besthi.reserve(sizeof(float) * npix));
     RT_HIP(hipMemsetAsync(sc->ws_counters.p, 0, 64, st));
     // the sweep keeps its per-pixel state in memory: no candidates yet, no certain hit yet (+inf)
-    RT_HIP(hipMemsetAsync(sc->ws_cnt.p, 0, sizeof(int32_t) * slots, st));
-    RT_HIP(hipMemsetD32Async((hipDeviceptr_t)sc->ws_besthi.p, 0x7F800000, slots, st));
+    RT_HIP(hipMemsetAsync(sc->ws_cnt.p, 0, sizeof(int32_t) * npix, st));
+    RT_HIP(hipMemsetD32Async((hipDeviceptr_t)sc->ws_besthi.p, 0x7F800000, npix, st));
 
     // planes for rays from the eye; the constant z of the pixel-grid directions is folded in
     const double ez = (double)(W / 2) / tan_half;       // driver.c:133
@@ -653,7 +654,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     a.ez = ez;
     a.cnt = sc->ws_cnt.as<int32_t>(); a.list = sc->ws_list.as<int32_t>();
     a.best_hi = sc->ws_besthi.as<float>();
-    a.chunks = chunks; a.chunk_stride = (long)npix;
+    a.chunks = chunks;
     a.waves_x = waves_x;
     a.tests = nullptr;
 #ifdef RT_RASTER_CHECK_INTERVAL
@@ -675,8 +676,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
 
     const ExactScene es = exact_of(sc);
     int* counters = sc->ws_counters.as<int>();
-    RT_TRY(rt_launch_resolve_primary(es, W, H, tan_half, rows, a.cnt, a.list, chunks, a.chunk_stride,
-                                     hit, tuv, sc->ws_ovf.as<int32_t>(), counters, st));
+    RT_TRY(rt_launch_resolve_primary(es, W, H, tan_half, rows, a.cnt, a.list, hit, tuv, sc->ws_ovf.as<int32_t>(), counters, st));
     RT_TRY(rt_launch_overflow_primary(es, W, H, tan_half, rows, sc->ws_ovf.as<int32_t>(), counters,
                                       hit, tuv, sc->ws_partials.p, st));
     RT_TRY(fetch_counters(counters, false));

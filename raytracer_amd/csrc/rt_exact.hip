@@ -91,38 +91,38 @@ struct Best {
     int idx;
 };
 
-// Confirmation of one ray's candidate lists (one per triangle chunk of the sweep, in ascending
-// triangle order).  Returns false when a list overflowed; ncand = candidates evaluated.
-template <bool ANYHIT>
+// Confirmation of one ray's candidate list (K slots, in any order).  The reference's loop runs
+// over ascending triangle numbers and replaces its winner only on `dist > 0 && dist < t`
+// (triangle_intersection.cu:167-176), i.e. it keeps the smallest t and, among equal t, the lowest
+// triangle number: that is the rule applied here, whatever order the candidates were listed in.
+// Returns false when the list overflowed; ncand = candidates evaluated.
+template <bool ANYHIT, int K>
 __device__ __forceinline__ bool confirm_list(const ExactScene& es, const double S[3],
                                              const double E[3], const int32_t* __restrict__ cnt,
-                                             const int32_t* __restrict__ list, long p, int chunks,
-                                             long chunk_stride, Best& best, bool& occluded,
-                                             int& ncand)
+                                             const int32_t* __restrict__ list, long p, Best& best,
+                                             bool& occluded, int& ncand)
 {
     best.t = 1e50;                  // triangle_intersection.cu:108
     best.idx = -1;
     best.u = best.v = 0;
     occluded = false;
     ncand = 0;
-    for (int c = 0; c < chunks; ++c) {
-        int n = cnt[c * chunk_stride + p];
-        if (ANYHIT && (n & RT_CNT_OCCLUDED)) {
-            occluded = true;
-            return true;
-        }
-        n &= RT_CNT_MASK;
-        if (n > RT_LIST_K) return false;
-        ncand += n;
-        const int32_t* l = list + (c * chunk_stride + p) * RT_LIST_K;
-        for (int k = 0; k < n; ++k) {
-            const int i = l[k];
-            double u, v;
-            const double dist = exact_tri(es, i, S, E, u, v);
-            if ((dist > 0) && (dist < best.t)) {       // :169
-                best.t = dist; best.u = u; best.v = v; best.idx = i;
-                if (ANYHIT) { occluded = true; return true; }
-            }
+    int n = cnt[p];
+    if (ANYHIT && (n & RT_CNT_OCCLUDED)) {
+        occluded = true;
+        return true;
+    }
+    n &= RT_CNT_MASK;
+    if (n > K) return false;
+    ncand = n;
+    const int32_t* l = list + p * K;
+    for (int k = 0; k < n; ++k) {
+        const int i = l[k];
+        double u, v;
+        const double dist = exact_tri(es, i, S, E, u, v);
+        if ((dist > 0) && (dist < best.t || (dist == best.t && i < best.idx))) {       // :169
+            best.t = dist; best.u = u; best.v = v; best.idx = i;
+            if (ANYHIT) { occluded = true; return true; }
         }
     }
     return true;
@@ -146,8 +146,8 @@ constexpr int RESOLVE_GRID = 4096;      // grid-stride: workgroups of the resolv
 
 __global__ void __launch_bounds__(RT_WG)
 k_resolve_primary(ExactScene es, int W, int H, double tan_half, RowMap rows,
-                  const int32_t* __restrict__ cnt, const int32_t* __restrict__ list, int chunks,
-                  long chunk_stride, int32_t* __restrict__ hit, double* __restrict__ tuv,
+                  const int32_t* __restrict__ cnt, const int32_t* __restrict__ list,
+                  int32_t* __restrict__ hit, double* __restrict__ tuv,
                   int32_t* __restrict__ ovf, int* __restrict__ counters)
 {
     const long npix = (long)W * rows.rows;
@@ -159,7 +159,7 @@ k_resolve_primary(ExactScene es, int W, int H, double tan_half, RowMap rows,
         Best b;
         bool occ;
         int ncand;
-        if (!confirm_list<false>(es, S, E, cnt, list, p, chunks, chunk_stride, b, occ, ncand)) {
+        if (!confirm_list<false, RT_RASTER_LIST_K>(es, S, E, cnt, list, p, b, occ, ncand)) {
             ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
         } else {
             total += ncand;
@@ -190,7 +190,7 @@ k_resolve_rays(ExactScene es, int n, const double* __restrict__ Sa, const double
         Best b;
         bool occ;
         int ncand;
-        if (!confirm_list<ANYHIT>(es, S, E, cnt, list, p, 1, 0, b, occ, ncand)) {
+        if (!confirm_list<ANYHIT, RT_LIST_K>(es, S, E, cnt, list, p, b, occ, ncand)) {
             ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
             continue;
         }
@@ -493,7 +493,7 @@ constexpr int SINGLE_RAY_GRID = 256;
 }  // namespace
 
 int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_half, const RowMap& rows,
-                              const int32_t* cnt, const int32_t* list, int chunks, long chunk_stride,
+                              const int32_t* cnt, const int32_t* list,
                               int32_t* hit, double* tuv, int32_t* ovf, int* counters, hipStream_t st)
 {
     const long npix = (long)W * rows.rows;
@@ -501,7 +501,7 @@ int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_hal
     long wgs = (npix + RT_WG - 1) / RT_WG;
     if (wgs > RESOLVE_GRID) wgs = RESOLVE_GRID;
     hipLaunchKernelGGL(k_resolve_primary, dim3((unsigned)wgs), dim3(RT_WG),
-                       0, st, es, W, H, tan_half, rows, cnt, list, chunks, chunk_stride, hit, tuv, ovf, counters);
+                       0, st, es, W, H, tan_half, rows, cnt, list, hit, tuv, ovf, counters);
     return launched("resolve_primary");
 }
 

@@ -51,6 +51,7 @@ constexpr int RT_FLOP_PER_PAIR = 21;
 constexpr int RT_TILE = RT_TILE_TRIS;      // triangles per LDS tile of the sweep
 constexpr int RT_RPL = RT_RAYS_PER_LANE;   // rays per lane in the sweep
 constexpr int RT_LIST_K = 16;       // candidate slots per ray handed to the fp64 confirmation
+constexpr int RT_RASTER_LIST_K = 32;    // same for a pixel of the primary sweep, whose triangle chunks share one list
 constexpr int RT_TILE_W = 16 * RT_RPL;   // pixel tile of one workgroup: 2x2 waves of (8*RPL)x8
 constexpr int RT_TILE_H = 16;
 constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
@@ -247,12 +248,12 @@ struct SweepArgs {
     // entry k of light l's planes holds triangle tri_order[l * num_tris_padded + k] (nullptr: k)
     const int32_t* tri_order;
     // pixel-grid sweep only: the triangle range is cut into `chunks` equal parts that run as
-    // separate workgroups; chunk c keeps its counts and lists chunk_stride rays further on
+    // separate workgroups; the chunks of a pixel share its count, list and bound
     int chunks;
-    long chunk_stride;
-    int waves_x;            // pixel-grid sweep only: waves side by side in a workgroup tile (4, 2, 1)
-    // pixel-grid sweep only: per ray and chunk, the upper bound of the closest certain hit's t
-    // so far (+inf before the sweep); cnt[] must be zero before the sweep
+    int waves_x;            // pixel-grid sweep only: waves side by side in a workgroup tile (4, 2, 1),
+                            // or 0: the waves of the band are numbered row by row and dealt four to a workgroup
+    // pixel-grid sweep only: per pixel, the upper bound of the closest certain hit's t so far
+    // (+inf before the sweep); cnt[] must be zero before the sweep
     float* best_hi;
     unsigned long long* tests;   // pairs evaluated, accumulated per workgroup (may be nullptr)
 };
@@ -261,9 +262,11 @@ int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st);
 int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st);   // primary rays, closest hit
 // launch shape of the pixel-grid sweep for a band of W x rows pixels and `tiles` triangle tiles:
 // pixels per lane (<= RT_RASTER_RPL) and the number of triangle chunks (<= RT_RASTER_MAX_CHUNKS)
-constexpr int RT_RASTER_MAX_CHUNKS = 24;
+constexpr int RT_RASTER_MAX_CHUNKS = 512;
 // and how the four waves of a workgroup are laid out: waves_x (4, 2 or 1) side by side, the rest
-// below, i.e. workgroup tiles of (waves_x * RT_RASTER_COLS * pixels_per_lane) x (64 / waves_x) pixels
+// below, i.e. workgroup tiles of (waves_x * RT_RASTER_COLS * pixels_per_lane) x (64 / waves_x) pixels;
+// or waves_x = 0: the wave-sized pixel blocks of the band, numbered row by row, four consecutive
+// ones to a workgroup (at most three idle waves in the whole launch; the launcher's own choice)
 void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks, int* waves_x);
 // pixel-triangle pairs the working waves of that shape evaluate (a wave covers
 // RT_RASTER_COLS * pixels_per_lane x RT_TILE_H pixels; waves wholly off the image idle)
@@ -275,6 +278,10 @@ inline long rt_raster_pairs(int W, int rows, int pixels_per_lane, long tris)
 // workgroup tiles that shape needs to cover W x rows pixels
 inline long rt_raster_tiles(int W, int rows, int pixels_per_lane, int waves_x)
 {
+    if (waves_x == 0) {
+        const int ww = RT_RASTER_COLS * pixels_per_lane;
+        return ((long)((W + ww - 1) / ww) * ((rows + RT_TILE_H - 1) / RT_TILE_H) + 3) / 4;
+    }
     const int tw = waves_x * RT_RASTER_COLS * pixels_per_lane, th = RT_TILE_H * (4 / waves_x);
     return (long)((W + tw - 1) / tw) * ((rows + th - 1) / th);
 }
@@ -315,7 +322,7 @@ struct ExactScene {
     const double* tv;
 };
 int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_half, const RowMap& rows,
-                              const int32_t* cnt, const int32_t* list, int chunks, long chunk_stride,
+                              const int32_t* cnt, const int32_t* list,
                               int32_t* hit, double* tuv, int32_t* ovf, int* counters,
                               hipStream_t st);
 int rt_launch_resolve_rays(const ExactScene& es, int n, const double* S, const double* E,

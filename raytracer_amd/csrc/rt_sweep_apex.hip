@@ -74,13 +74,17 @@ __device__ __forceinline__ Tri2 load_tri2(const float4* p) { return {p[0], p[RT_
 // ------------------------------------------------------------------------------------------
 // What the sweep keeps per pixel lives in memory, not in registers: cnt[] (candidates listed so
 // far) and best_hi[] (upper bound of the true t of the closest certain hit so far).  Only the
-// rare path touches them, a pixel belongs to one lane, and the hot loop is left with few enough
-// registers for eight waves per SIMD.
+// rare path touches them, and the hot loop is left with few enough registers for eight waves
+// per SIMD.  The workgroups that sweep different triangle chunks for the same pixels share that
+// state: a candidate takes its list slot with an atomic increment, and best_hi only ever
+// decreases (atomic minimum on the bit pattern: the values are positive floats), so a certain hit
+// found in one chunk prunes the candidates of all the others.  The order of a pixel's list is
+// then arbitrary; the exact pass picks the winner by (t, triangle number), which is what the
+// reference's ascending loop with its strict '<' keeps (triangle_intersection.cu:167-176).
 __device__ __forceinline__ void push_mem(const SweepArgs& A, long slot, int tri)
 {
-    const int c = A.cnt[slot];
-    if (c < RT_LIST_K) A.list[slot * RT_LIST_K + c] = tri;
-    A.cnt[slot] = c + 1;
+    const int c = atomicAdd(&A.cnt[slot], 1);
+    if (c < RT_RASTER_LIST_K) A.list[slot * RT_RASTER_LIST_K + c] = tri;
 }
 
 // The rest of the inside test for one pixel that passed the sign tests of triangle `tri`
@@ -112,11 +116,15 @@ __device__ __forceinline__ void finish_raster(const SweepArgs& A, long slot, int
     const float T = Hh.w, eT = U22 * __builtin_fabsf(T);
     const float t = T / d;          // rays start at the apex: t0 = 0
     const float terr = (eT + __builtin_fabsf(t) * en) / den * 1.000001f + U22 * __builtin_fabsf(t);
-    const float best_hi = A.best_hi[slot];
+    // (an agent-scope load: another chunk's workgroup may have lowered the bound; a stale value
+    // would only prune less)
+    const float best_hi = __int_as_float(__hip_atomic_load(reinterpret_cast<const int*>(A.best_hi + slot),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (!(t >= -terr) || !(t - terr <= best_hi)) return;
     push_mem(A, slot, tri);
     // a certain hit (inside by the full margin, t resolved) bounds the closest hit's t from above
-    if (m3 >= margin * ad && t > terr && t + terr < best_hi) A.best_hi[slot] = t + terr;
+    if (m3 >= margin * ad && t > terr && t + terr < best_hi)
+        atomicMin(reinterpret_cast<int*>(A.best_hi + slot), __float_as_int(t + terr));
 }
 
 template <int R>
@@ -135,18 +143,28 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
     static_assert(64 / COLS == RT_TILE_H, "a wave covers RT_TILE_H rows");
     // the four waves: waves_x side by side, the rest below (whichever wastes fewer pixels beyond
     // the image's right and bottom edges)
-    const int wx = A.waves_x, tile_w = wx * (COLS * R), tile_h = RT_TILE_H * (4 / wx);
-    const int tiles_x = (A.W + tile_w - 1) / tile_w;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int wave_x0 = txi * tile_w + (wave & (wx - 1)) * (COLS * R);
-    const int wave_y0 = tyi * tile_h + (wave / wx) * RT_TILE_H;
+    // ... or, waves_x = 0, the wave-sized blocks of the band numbered row by row and dealt four
+    // to a workgroup: no idle waves but in the last workgroup
+    int wave_x0, wave_y0;
+    if (A.waves_x == 0) {
+        const int cols = (A.W + COLS * R - 1) / (COLS * R);
+        const int w = blockIdx.x * 4 + wave, wy = w / cols;
+        wave_x0 = (w - wy * cols) * (COLS * R);
+        wave_y0 = wy * RT_TILE_H;
+    } else {
+        const int wx = A.waves_x, tile_w = wx * (COLS * R), tile_h = RT_TILE_H * (4 / wx);
+        const int tiles_x = (A.W + tile_w - 1) / tile_w;
+        const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+        wave_x0 = txi * tile_w + (wave & (wx - 1)) * (COLS * R);
+        wave_y0 = tyi * tile_h + (wave / wx) * RT_TILE_H;
+    }
     const int px0 = wave_x0 + (lane % COLS);
     const int lr = wave_y0 + lane / COLS;                           // local row of the call's row set
     // a wave that lies wholly beyond the image's right or bottom edge only helps to stage tiles
     const bool wave_on = __builtin_amdgcn_readfirstlane((wave_x0 < A.W && wave_y0 < A.rows.rows) ? 1 : 0) != 0;
     const float Y = (float)(A.rows.image_row(lr) - A.H / 2);        // driver.c:132
-    // ray number: local pixel, in the segment of this workgroup's triangle chunk
-    const long slot0 = (long)blockIdx.y * A.chunk_stride + (long)lr * A.W + px0;
+    // ray number: local pixel (the triangle chunks of a pixel share its count, list and bound)
+    const long slot0 = (long)lr * A.W + px0;
 
     // pixel r of the lane has X = px0 + COLS r - W/2 (driver.c:131); the planes carry COLS p.x,
     // so the sweep works with X / COLS = Xs0 + r (exact in fp32)
@@ -669,14 +687,9 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     const long slots = 5L * device_cus();           // resident workgroups
     int max_chunks = tiles / 8;
     if (max_chunks < 1) max_chunks = 1;
-    // every chunk keeps candidate lists of its own (72 bytes per pixel): RT_RASTER_MAX_CHUNKS for
-    // a full frame, up to four times as many where the pixels are few (an eighth of a 4K frame
-    // fills the machine better with 96 short chunks of 32-pixel lanes: 52 ms against 54.5)
+    // (the chunks of a pixel share its candidate list, so their number costs no memory)
     static const int env_cap = getenv("RT_AMD_RASTER_MAX_CHUNKS") ? atoi(getenv("RT_AMD_RASTER_MAX_CHUNKS")) : 0;
-    long cap = 200000000L / ((long)W * rows > 0 ? (long)W * rows : 1);
-    if (cap > 4 * RT_RASTER_MAX_CHUNKS) cap = 4 * RT_RASTER_MAX_CHUNKS;
-    if (cap < RT_RASTER_MAX_CHUNKS) cap = RT_RASTER_MAX_CHUNKS;
-    if (env_cap > 0) cap = env_cap;
+    const long cap = env_cap > 0 ? env_cap : RT_RASTER_MAX_CHUNKS;
     if (max_chunks > cap) max_chunks = (int)cap;
     // pixels the workgroup tiles cover, and the wave layout that covers the fewest (waves wholly
     // beyond the image's edges do no arithmetic, but they hold registers and LDS)
@@ -686,12 +699,11 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     };
     // pixels the working waves cover: what the arithmetic is paid for
     auto swept = [&](int r) { return rt_raster_pairs(W, rows, r, 1); };
-    auto best_layout = [&](int r) {
-        int wx = 4;
-        if (covered(r, 2) < covered(r, wx)) wx = 2;
-        if (covered(r, 1) < covered(r, wx)) wx = 1;
-        return wx;
-    };
+    // the row-by-row dealing of the waves leaves at most three of them idle in the whole launch
+    // (an idle wave does no arithmetic but keeps its slot on a SIMD whose issue rate needs all
+    // eight); the rectangular layouts remain for forced shapes
+    auto best_layout = [&](int) { return 0; };
+    (void)covered;
     if (const char* force = getenv("RT_AMD_RASTER_FORCE")) {
         int fr = 0, fc = 0, fw = 0;
         const int n = sscanf(force, "%d,%d,%d", &fr, &fc, &fw);
@@ -699,7 +711,7 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
             (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == 16 || fr == 32 || fr == 64) && fr <= RT_RASTER_RPL) {
             *pixels_per_lane = fr;
             *chunks = fc;
-            *waves_x = (n == 3 && (fw == 1 || fw == 2 || fw == 4)) ? fw : best_layout(fr);
+            *waves_x = (n == 3 && (fw == 0 || fw == 1 || fw == 2 || fw == 4)) ? fw : best_layout(fr);
             return;
         }
     }
@@ -720,7 +732,8 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
         const int wx = best_layout(r);
         const long wgs = rt_raster_tiles(W, rows, r, wx);
         if (wgs * max_chunks >= slots || r == 1) {
-            long c = (24 * slots + wgs - 1) / wgs;      // about 24 rounds are fine-grained enough
+            static const int rounds = getenv("RT_AMD_RASTER_ROUNDS") ? atoi(getenv("RT_AMD_RASTER_ROUNDS")) : 24;
+            long c = (rounds * slots + wgs - 1) / wgs;  // about 24 rounds are fine-grained enough
             if (c > max_chunks) c = max_chunks;
             if (c < 1) c = 1;
             *pixels_per_lane = r;
@@ -746,7 +759,7 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
     }
     int r = 1, chunks = 1, wx = 4;
     rt_raster_shape(a.W, a.rows.rows, (a.tri_end - a.tri_begin) / RT_TILE, &r, &chunks, &wx);
-    if (a.chunks != chunks || a.waves_x != wx || (chunks > 1 && a.chunk_stride < (long)a.W * a.rows.rows)) {
+    if (a.chunks != chunks || a.waves_x != wx) {
         rt_set_error("raster sweep: caller and launcher disagree on the launch shape (%d chunks, %d waves "
                      "side by side vs %d, %d)", a.chunks, a.waves_x, chunks, wx);
         return RT_E_ARG;
