@@ -196,14 +196,22 @@ extern "C" int rt_scene_create(rt_scene** out)
 extern "C" int rt_scene_destroy(rt_scene* sc)
 {
     if (!sc) return RT_OK;
+    if (sc->side_stream) {
+        (void)hipStreamSynchronize(sc->side_stream);
+        (void)hipStreamDestroy(sc->side_stream);
+        (void)hipEventDestroy(sc->ev_fork);
+        (void)hipEventDestroy(sc->ev_join);
+    }
     DevBuf* bufs[] = {&sc->ox, &sc->oy, &sc->oz, &sc->ex, &sc->ey, &sc->ez, &sc->nx, &sc->ny, &sc->nz,
                       &sc->tu, &sc->tv, &sc->iA, &sc->iB, &sc->iC, &sc->iAn, &sc->iBn, &sc->iCn,
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts,
-                      &sc->scratch_max, &sc->mat_dev, &sc->ws_partials, &sc->ws_frame, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi,
+                      &sc->scratch_max, &sc->mat_dev, &sc->ws_partials, &sc->ws_frame, &sc->planes_light, &sc->ws_sort_tri, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
                       &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort, &sc->tri_order};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : sc->tex_data) b.release();
+    if (sc->h_counts) (void)hipHostFree(sc->h_counts);
+    for (hipEvent_t e : sc->count_events) (void)hipEventDestroy(e);
     delete sc;
     return RT_OK;
 }
@@ -645,7 +653,8 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     const double ez = (double)(W / 2) / tan_half;       // driver.c:133
     const double eye[3] = {0, 0, 0};                    // driver.c:121-123
     const double hw = 0.5 * W + 1, hh = 0.5 * H + 1;
-    RT_TRY(rt_launch_pack_apex(sc, eye, ez, sqrt(hw * hw + hh * hh + ez * ez), 0, true, nullptr, st));
+    RT_TRY(rt_launch_pack_apex(sc, eye, ez, sqrt(hw * hw + hh * hh + ez * ez), sc->planes_apex.as<float4>(), true,
+                               nullptr, st));
 
     SweepArgs a{};
     a.planes = sc->planes_apex.as<float4>(); a.plane_stride = sc->num_tris_padded;
@@ -713,6 +722,8 @@ extern "C" int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int
 //   * shadow rays of the pixel loop: `sets` lists (light x dominant axis, binned beforehand
 //     into ws_act0 with their sizes in ws_live), indexed from the first range on.
 // launch(a) starts one range for all sets.
+constexpr int kCountSlots = 48;     // ranges of one any-hit sweep whose counts can be in flight
+
 template <class Launch>
 static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride, bool binned,
                          Launch&& launch)
@@ -728,17 +739,43 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
     int first = np / first_div;
     first = ((first + RT_TILE - 1) / RT_TILE) * RT_TILE;
     if (first < 16 * RT_TILE) first = 16 * RT_TILE;
-    int counts[RT_APEX_SETS];
+    if (!sc->h_counts) {
+        RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&sc->h_counts), sizeof(int) * RT_APEX_SETS * kCountSlots,
+                             hipHostMallocDefault));
+        sc->count_events.resize(kCountSlots);
+        for (hipEvent_t& e : sc->count_events) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    // The host only needs the survivor counts to size the next launches (grid, rays per lane,
+    // triangle chunks) and to stop early; the kernels read the counts themselves on the device.
+    // So the counts of a compaction are copied to page-locked memory behind it on the stream,
+    // and the host sizes range k + 1 from the counts that were valid BEFORE range k -- an upper
+    // bound, since rays only ever retire -- which have long arrived while range k is still running:
+    // the host never waits for the device between ranges, and a workgroup beyond the real
+    // count returns at once.
     int live = n;
     long total = (long)n * sets;
-    auto fetch_counts = [&](const int* dev) -> int {
-        RT_HIP(hipMemcpyAsync(counts, dev, sizeof(int) * sets, hipMemcpyDeviceToHost, st));
-        RT_HIP(hipStreamSynchronize(st));
-        live = 0; total = 0;
-        for (int k = 0; k < sets; ++k) { live = counts[k] > live ? counts[k] : live; total += counts[k]; }
+    long est = total, prev_total = 0;       // estimate of the rays really alive (see SweepArgs::est_rays)
+    auto post_counts = [&](const int* dev, int slot) -> int {
+        RT_HIP(hipMemcpyAsync(sc->h_counts + (size_t)slot * RT_APEX_SETS, dev, sizeof(int) * sets,
+                              hipMemcpyDeviceToHost, st));
+        RT_HIP(hipEventRecord(sc->count_events[slot], st));
         return RT_OK;
     };
-    if (binned) RT_TRY(fetch_counts(live_dev[0]));
+    auto take_counts = [&](int slot) -> int {
+        RT_HIP(hipEventSynchronize(sc->count_events[slot]));
+        const int* c = sc->h_counts + (size_t)slot * RT_APEX_SETS;
+        prev_total = total;
+        live = 0; total = 0;
+        for (int k = 0; k < sets; ++k) { live = c[k] > live ? c[k] : live; total += c[k]; }
+        est = total;
+        return RT_OK;
+    };
+    int slot_next = 0;          // slot the next post goes to
+    if (binned) {               // the sizes of the binned lists: these the host does wait for
+        RT_TRY(post_counts(live_dev[0], slot_next));
+        RT_TRY(take_counts(slot_next));
+        ++slot_next;
+    }
     // a sweep of a few milliseconds is not worth the compaction round trips
     // (RT_AMD_RANGE_MIN_WORK, read at every call: tests set it to 0 to run ranges on small inputs)
     const char* min_work_env = getenv("RT_AMD_RANGE_MIN_WORK");
@@ -750,10 +787,13 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
     // as seen from the light first (rt_sort.hip)
     static const bool sort_rays = !(getenv("RT_AMD_SORT_RAYS") && atoi(getenv("RT_AMD_SORT_RAYS")) == 0);
     if (binned && sort_rays && first < np && total > 0) {
-        RT_TRY(rt_launch_sort_rays(sc, a.S, a.E, act[0], act[1], counts, live_dev[0], sets, stride, st));
+        RT_TRY(rt_launch_sort_rays(sc, a.S, a.E, act[0], act[1], sc->h_counts, live_dev[0], sets, stride, st));
         RT_HIP(hipMemcpyAsync(live_dev[1], live_dev[0], sizeof(int) * RT_APEX_SETS, hipMemcpyDeviceToDevice, st));
         cur = 1;
     }
+    // with the profiling events on every launch is followed by a sync anyway: use exact counts
+    static const bool lagged_env = !(getenv("RT_AMD_RANGE_SYNC") && atoi(getenv("RT_AMD_RANGE_SYNC")) != 0);
+    int posted = -1;            // slot of the counts the most recent compaction produced
     while (begin < np && live > 0) {
         int end = begin + len;
         if (end > np || np - end < len / 2) end = np;
@@ -761,8 +801,9 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
         a.resume = begin > 0;
         a.active = indexed ? act[cur] : nullptr;
         a.live_counts = indexed ? live_dev[cur] : nullptr;
-        a.n_rays = indexed ? live : n;          // indexed: the largest set, sizes the grid
+        a.n_rays = indexed ? live : n;          // indexed: (a bound on) the largest set, sizes the grid
         a.total_rays = total;
+        a.est_rays = est;
         a.lights = sets;
         a.light_ray_stride = stride;
         const double ms0 = rt_g().prof.shadow_ms;
@@ -771,19 +812,32 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
         if (getenv("RT_AMD_TRACE_PASSES")) {
             const double ms = rt_g().prof.shadow_ms - ms0;
             const double tests = (double)(rt_g().prof.shadow_tests - tests0);
-            fprintf(stderr, "rt_amd: any-hit range [%d,%d) over %d set(s), %ld rays, largest %d: %.3f ms, "
-                            "%.3e tests (%.0f%% of rays x triangles), %.2e tests/s\n", begin, end, sets, total,
-                    indexed ? live : n, ms, tests, 100.0 * tests / ((double)total * (end - begin) + 1e-9),
-                    ms > 0 ? tests / (ms * 1e-3) : 0.0);
+            fprintf(stderr, "rt_amd: any-hit range [%d,%d) over %d set(s), at most %ld rays, largest set at most %d: %.3f ms, "
+                            "%.3e tests, %.2e tests/s\n", begin, end, sets, total,
+                    indexed ? live : n, ms, tests, ms > 0 ? tests / (ms * 1e-3) : 0.0);
         }
         begin = end;
         if (begin >= np) break;
+        // the counts the compaction before this range produced have arrived by now: they bound
+        // the survivors of this range too
+        if (posted >= 0) RT_TRY(take_counts(posted));
         // compact the survivors (from the full set the first time in the unbinned case)
         RT_HIP(hipMemsetAsync(live_dev[cur ^ 1], 0, sizeof(int) * RT_APEX_SETS, st));
         RT_TRY(rt_launch_compact(a.cnt, indexed ? act[cur] : nullptr, indexed ? live_dev[cur] : nullptr,
                                  indexed ? live : n, sets, stride, cnt_div, act[cur ^ 1], live_dev[cur ^ 1],
                                  st));
-        RT_TRY(fetch_counts(live_dev[cur ^ 1]));
+        posted = slot_next % kCountSlots;
+        ++slot_next;
+        RT_TRY(post_counts(live_dev[cur ^ 1], posted));
+        if (!lagged_env || rt_g().profiling) {
+            RT_TRY(take_counts(posted));      // exact counts, host waits
+        } else if (prev_total > 0) {
+            // `total` counts the rays that went into the range just launched; expect the range to
+            // thin them out like the one before it did
+            double keep = (double)total / (double)prev_total;
+            keep = keep < 0.25 ? 0.25 : (keep > 1.0 ? 1.0 : keep);
+            est = (long)(total * keep);
+        }
         cur ^= 1;
         indexed = true;
         len = (int)(len * growth + RT_TILE - 1) / RT_TILE * RT_TILE;
@@ -851,11 +905,55 @@ static int trace_rays_impl(rt_scene* sc, const RayWorkspace* static_ws, int n, c
     return resolve_rays(sc, ws, n, S, E, anyhit, hit, tuv, point, occ);
 }
 
+// Plane sets of lights [l0, l0 + lights) for one any-hit launch, on stream st: every light's
+// triangles in the order of the solid angle they subtend at it (rt_sort.hip: occluded rays meet
+// an occluder sooner), packed relative to the light.  |D'| <= sqrt(3) for a direction scaled to a
+// unit dominant component.
+static int prepare_lights(rt_scene* sc, const rt_frame* f, int l0, int lights, hipStream_t st)
+{
+    static const bool sort_tris = !(getenv("RT_AMD_SORT_TRIS") && atoi(getenv("RT_AMD_SORT_TRIS")) == 0);
+    const size_t set_planes = (size_t)RT_APEX_PLANES * sc->num_tris_padded;
+    for (int k = 0; k < lights; ++k) {
+        int32_t* ord = sort_tris ? sc->tri_order.as<int32_t>() + (size_t)k * sc->num_tris_padded : nullptr;
+        if (ord) RT_TRY(rt_launch_sort_triangles(sc, f->light_in_eye_space[l0 + k], ord, st));
+        RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l0 + k], 1.0, 1.75,
+                                   sc->planes_light.as<float4>() + k * set_planes, false, ord, st));
+    }
+    return RT_OK;
+}
+
+static int reserve_light_buffers(rt_scene* sc, int lights)
+{
+    RT_TRY(sc->planes_light.reserve(sizeof(float4) * (size_t)sc->num_tris_padded * RT_APEX_PLANES * lights));
+    RT_TRY(sc->tri_order.reserve(sizeof(int32_t) * (size_t)sc->num_tris_padded * lights));
+    return RT_OK;
+}
+
+// Starts prepare_lights for the first group of lights on the scene's side stream, behind
+// everything already queued on the launch stream: the sorts and packs (bandwidth-bound, well
+// under a millisecond) then run beside the primary sweep (instruction-bound) instead of after
+// it.  The any-hit phase waits for ev_join.
+static int prepare_lights_aside(rt_scene* sc, const rt_frame* f, int lights)
+{
+    hipStream_t st = rt_g().stream;
+    if (!sc->side_stream) {
+        RT_HIP(hipStreamCreateWithFlags(&sc->side_stream, hipStreamNonBlocking));
+        RT_HIP(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
+        RT_HIP(hipEventCreateWithFlags(&sc->ev_join, hipEventDisableTiming));
+    }
+    RT_TRY(reserve_light_buffers(sc, lights));
+    RT_HIP(hipEventRecord(sc->ev_fork, st));
+    RT_HIP(hipStreamWaitEvent(sc->side_stream, sc->ev_fork, 0));
+    const int rc = prepare_lights(sc, f, 0, lights, sc->side_stream);
+    RT_HIP(hipEventRecord(sc->ev_join, sc->side_stream));      // also after a failed launch: the join must not hang
+    return rc;
+}
+
 // Shadow rays of the pixel loop: [light][pixel] rays that end at their light (k_shadow_setup).
 // Apex sweeps over planes packed relative to each light (rt_sweep_apex.hip), RT_APEX_LIGHTS
 // lights per launch; the rays of a light are binned by the dominant axis of their direction.
 static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, int row_block,
-                             const double* S, const double* E, uint8_t* occ)
+                             const double* S, const double* E, uint8_t* occ, bool first_group_aside)
 {
     hipStream_t st = rt_g().stream;
     const size_t npix = (size_t)W * nrows;
@@ -871,25 +969,18 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
     }
     for (int l0 = 0; l0 < L; l0 += RT_APEX_LIGHTS) {
         const int lights = L - l0 < RT_APEX_LIGHTS ? L - l0 : RT_APEX_LIGHTS;
-        RT_TRY(sc->planes_apex.reserve(sizeof(float4) * (size_t)sc->num_tris_padded * RT_APEX_PLANES * lights));
         RT_TRY(anyhit_buffers(sc, npix * 3 * (size_t)lights));
-        // |D'| <= sqrt(3) for a direction scaled to a unit dominant component
-        // every light's planes in the order of the solid angle the triangles subtend at it
-        // (rt_sort.hip): occluded rays meet an occluder sooner
+        if (l0 == 0 && first_group_aside) {
+            RT_HIP(hipStreamWaitEvent(st, sc->ev_join, 0));     // prepare_lights_aside
+        } else {
+            RT_TRY(reserve_light_buffers(sc, lights));
+            RT_TRY(prepare_lights(sc, f, l0, lights, st));
+        }
         static const bool sort_tris = !(getenv("RT_AMD_SORT_TRIS") && atoi(getenv("RT_AMD_SORT_TRIS")) == 0);
-        int32_t* order = nullptr;
-        if (sort_tris) {
-            RT_TRY(sc->tri_order.reserve(sizeof(int32_t) * (size_t)sc->num_tris_padded * lights));
-            order = sc->tri_order.as<int32_t>();
-        }
-        for (int k = 0; k < lights; ++k) {
-            int32_t* ord = order ? order + (size_t)k * sc->num_tris_padded : nullptr;
-            if (ord) RT_TRY(rt_launch_sort_triangles(sc, f->light_in_eye_space[l0 + k], ord, st));
-            RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l0 + k], 1.0, 1.75, k, false, ord, st));
-        }
+        int32_t* order = sort_tris ? sc->tri_order.as<int32_t>() : nullptr;
         SweepArgs a{};
         a.tri_order = order;
-        a.planes = sc->planes_apex.as<float4>(); a.plane_stride = sc->num_tris_padded;
+        a.planes = sc->planes_light.as<float4>(); a.plane_stride = sc->num_tris_padded;
         a.light_plane_stride = (long)RT_APEX_PLANES * sc->num_tris_padded;
         a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
         a.S = S + 3 * npix * (size_t)l0; a.E = E + 3 * npix * (size_t)l0;
@@ -998,6 +1089,10 @@ static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, doubl
 
     if (!hit) { RT_TRY(sc->ws_hit.reserve(sizeof(int32_t) * npix)); hit = sc->ws_hit.as<int32_t>(); }
     if (!tuv) { RT_TRY(sc->ws_tuv.reserve(sizeof(double) * 3 * npix)); tuv = sc->ws_tuv.as<double>(); }
+    // the first group of lights is sorted and packed on a side stream beside the primary sweep
+    static const bool aside_env = !(getenv("RT_AMD_LIGHTS_ASIDE") && atoi(getenv("RT_AMD_LIGHTS_ASIDE")) == 0);
+    const bool aside = L > 0 && aside_env;
+    if (aside) RT_TRY(prepare_lights_aside(sc, f, L < RT_APEX_LIGHTS ? L : RT_APEX_LIGHTS));
     RT_TRY(trace_primary_rows(sc, W, H, tan_half, rows, hit, tuv));
 
     // frame constants
@@ -1039,7 +1134,7 @@ static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, doubl
         a.occ = sc->ws_occ.as<uint8_t>();
         RT_TRY(rt_launch_shadow_setup(a, st));
         RT_TRY(trace_shadow_rays(sc, f, W, rows.rows, rows.parts > 1 ? rows.block : rows.rows, a.shS, a.shE,
-                                 sc->ws_occ.as<uint8_t>()));
+                                 sc->ws_occ.as<uint8_t>(), aside));
     }
     RT_TRY(rt_launch_shade_final(a, st));
     RT_HIP(hipStreamSynchronize(st));

@@ -124,9 +124,19 @@ struct rt_scene {
     DevBuf planes;
     // same for the apex sweeps: RT_APEX_PLANES planes, repacked for the eye and for each light
     DevBuf planes_apex, tri_order;
+    // ... and for the lights of one any-hit launch (RT_APEX_LIGHTS sets side by side), sorted and
+    // packed on a side stream while the primary sweep runs
+    DevBuf planes_light, ws_sort_tri;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf tri_verts;           // 9 doubles per triangle, eye space (see ExactScene::tv)
     DevBuf scratch_max;         // 1 float: max |coordinate| of the eye-space vertices
     DevBuf mat_dev;             // the 4x4 of the current transform
+
+    // survivor counts of the any-hit ranges travel to page-locked host memory behind the launch
+    // stream, one slot and one event per range (rt_api.hip: anyhit_ranges)
+    int* h_counts = nullptr;
+    std::vector<hipEvent_t> count_events;
 
     // per-call workspaces (grow-only)
     DevBuf ws_cnt, ws_list, ws_ovf, ws_counters, ws_besthi, ws_partials, ws_frame;
@@ -173,9 +183,10 @@ int rt_launch_transform(const double* m16, const double* x, const double* y, con
 int rt_launch_pack(rt_scene* sc, hipStream_t st);
 // apex planes for rays through `apex`; zs is folded into the z components (the constant z of
 // pixel-grid directions, 1 otherwise); dmax bounds |D| of every ray of the sweep
-int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, int set,
+int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, float4* dst,
                         bool sign_layout, const int32_t* order, hipStream_t st);
-// into plane set `set` of sc->planes_apex; order (or nullptr): entry k holds triangle order[k]
+// into the RT_APEX_PLANES planes of num_tris_padded entries at dst; order (or nullptr): entry k
+// holds triangle order[k]
 
 // The pixel rows one call works on: one block of `block` rows out of every `parts` (rt_rows in
 // the public header); parts = 1 is the contiguous band [y0, y0 + rows).  Outputs are indexed by
@@ -244,6 +255,8 @@ struct SweepArgs {
     long light_ray_stride, light_plane_stride;
     const int* live_counts;
     long total_rays;
+    long est_rays;          // the host's estimate of the rays really alive (<= total_rays; 0: unknown):
+                            // picks rays per lane and triangle chunks, never an array bound
     int32_t* occ_id;        // per ray (laid out like cnt): the triangle of its certain hit, or nullptr
     // entry k of light l's planes holds triangle tri_order[l * num_tris_padded + k] (nullptr: k)
     const int32_t* tri_order;

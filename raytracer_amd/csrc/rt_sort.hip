@@ -99,11 +99,11 @@ int rt_launch_sort_triangles(rt_scene* sc, const double apex[3], int32_t* order,
         return RT_E_HIP;
     }
     const size_t arr = ((size_t)np * 4 + 255) & ~(size_t)255;
-    if (int rc = sc->ws_sort.reserve(3 * arr + temp_bytes)) return rc;
-    unsigned* keys_in = sc->ws_sort.as<unsigned>();
-    unsigned* keys_out = reinterpret_cast<unsigned*>(sc->ws_sort.as<char>() + arr);
-    int32_t* ids_in = reinterpret_cast<int32_t*>(sc->ws_sort.as<char>() + 2 * arr);
-    void* temp = sc->ws_sort.as<char>() + 3 * arr;
+    if (int rc = sc->ws_sort_tri.reserve(3 * arr + temp_bytes)) return rc;
+    unsigned* keys_in = sc->ws_sort_tri.as<unsigned>();
+    unsigned* keys_out = reinterpret_cast<unsigned*>(sc->ws_sort_tri.as<char>() + arr);
+    int32_t* ids_in = reinterpret_cast<int32_t*>(sc->ws_sort_tri.as<char>() + 2 * arr);
+    void* temp = sc->ws_sort_tri.as<char>() + 3 * arr;
     hipLaunchKernelGGL(k_tri_keys, dim3((np + RT_WG - 1) / RT_WG), dim3(RT_WG), 0, st, sc->ex.as<double>(),
                        sc->ey.as<double>(), sc->ez.as<double>(), sc->iA.as<int>(), sc->iB.as<int>(),
                        sc->iC.as<int>(), sc->num_tris, (int)np, apex[0], apex[1], apex[2], keys_in, ids_in);

@@ -789,7 +789,7 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
 // memory.)
 static int apex_max_chunks(int tiles)
 {
-    static const int cap = getenv("RT_AMD_APEX_MAX_CHUNKS") ? atoi(getenv("RT_AMD_APEX_MAX_CHUNKS")) : 64;
+    static const int cap = getenv("RT_AMD_APEX_MAX_CHUNKS") ? atoi(getenv("RT_AMD_APEX_MAX_CHUNKS")) : 256;
     int c = tiles / 8;
     if (c > cap) c = cap;
     return c < 1 ? 1 : c;
@@ -831,7 +831,9 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
     if (a.n_rays <= 0) return RT_OK;
     const int tiles = (a.tri_end - a.tri_begin) / RT_TILE;
     const int max_chunks = apex_max_chunks(tiles);
-    int r = apex_rays_per_lane(a.total_rays > 0 ? a.total_rays : (long)a.n_rays * a.lights, max_chunks);
+    // shape from the host's estimate of the live rays where it has one (the bound may be a range stale)
+    const long shape_rays = a.est_rays > 0 ? a.est_rays : (a.total_rays > 0 ? a.total_rays : (long)a.n_rays * a.lights);
+    int r = apex_rays_per_lane(shape_rays, max_chunks);
     int forced_chunks = 0;
     // RT_AMD_APEX_FORCE="<rays per lane>,<chunks>": tests run every kernel shape on small inputs
     if (const char* force = getenv("RT_AMD_APEX_FORCE")) {
@@ -844,7 +846,7 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
     }
     const int per_wg = RT_WG * r;
     const unsigned wgs = (unsigned)((a.n_rays + per_wg - 1) / per_wg);
-    const long all_wgs = a.total_rays > 0 ? (a.total_rays + per_wg - 1) / per_wg + a.lights : (long)wgs * a.lights;
+    const long all_wgs = (shape_rays + per_wg - 1) / per_wg + a.lights;
     const dim3 grid(wgs, a.lights, forced_chunks ? forced_chunks : apex_chunks(all_wgs, max_chunks));
     switch (r) {
     case 1: return launch(k_sweep_apex<1>, a, grid, st, "apex sweep");

@@ -233,19 +233,19 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
 
 }  // namespace
 
-int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, int set,
+int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, float4* dst,
                         bool sign_layout, const int32_t* order, hipStream_t st)
 {
     const int np = sc->num_tris_padded;
-    if (set < 0 || set >= RT_APEX_SETS) {
-        rt_set_error("apex pack: plane set %d out of range", set);
+    if (!dst) {
+        rt_set_error("apex pack: no plane buffer");
         return RT_E_ARG;
     }
     hipLaunchKernelGGL(k_pack_apex, dim3((np + RT_WG - 1) / RT_WG), dim3(RT_WG), 0, st,
                        sc->ex.as<double>(), sc->ey.as<double>(), sc->ez.as<double>(),
                        sc->iA.as<int>(), sc->iB.as<int>(), sc->iC.as<int>(), sc->num_tris, np,
                        sc->scratch_max.as<unsigned>(), apex[0], apex[1], apex[2], zs, dmax,
-                       sign_layout ? 1 : 0, order, sc->planes_apex.as<float4>() + (size_t)set * RT_APEX_PLANES * np);
+                       sign_layout ? 1 : 0, order, dst);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("apex pack launch failed: %s", hipGetErrorString(e));
