@@ -71,6 +71,7 @@ const char* rt_version(void);
 int         rt_set_stream(void* hip_stream);     /* NULL = the default stream */
 
 typedef struct rt_scene rt_scene;                /* device-resident mesh, opaque */
+typedef struct rt_obj rt_obj;                    /* a loaded .obj file (host side), opaque */
 
 /* Lights and matrices of one frame: the light_model.h:4-8 globals plus the obinv of
  * driver.c:107 that interpolate_normal_vector consumes. */
@@ -200,6 +201,30 @@ int rt_render_rows_part(rt_scene* sc, const rt_frame* f, int W, int H, double ta
                         const rt_rows* rows, int32_t* hit, double* tuv, double* argb, uint8_t* rgb8);
 int rt_place_rows_part(const uint8_t* rgb8, int W, int H, const rt_rows* rows, uint8_t* screen);
 
+/* One frame on several GPUs of one node, from one process.  The reference drives a single GPU
+ * (triangle_intersection.cu:98-190); its pixel loop (driver.c:126-193) shards by rows because
+ * pixels are independent.  An rt_multi holds one scene per device (every device keeps the full
+ * mesh), renders part i of n_devices interleaved 16-row parts on device i (one host thread per
+ * device inside the call; the interface stays blocking and single-caller), moves the finished
+ * 8-bit rows to the first device over RCCL (one group of ncclSend / ncclRecv, xGMI point to
+ * point) and places them there (driver.c:186-190).  RCCL is loaded at run time, and only for more
+ * than one device.  Not usable while a user stream is set (rt_set_stream).
+ *   devices        n_devices HIP ordinals, or NULL for 0 .. n_devices-1
+ *   for_each_scene calls fn(scene of part i, i, user) with that scene's device current, one after
+ *                  the other, for the rt_scene_set_* uploads; rt_multi_set_obj does it for a loaded
+ *                  OBJ file
+ *   transform      rt_scene_transform(obmat) on every device (driver.c:110)
+ *   render         screen: W*H*3 bytes on the FIRST device, top row first; cleared and filled */
+typedef struct rt_multi rt_multi;
+int rt_multi_create(rt_multi** out, int n_devices, const int* devices);
+int rt_multi_destroy(rt_multi* m);
+int rt_multi_num_devices(const rt_multi* m);
+int rt_multi_for_each_scene(rt_multi* m, int (*fn)(rt_scene* scene, int part, void* user), void* user);
+int rt_multi_set_obj(rt_multi* m, const rt_obj* o);
+int rt_multi_transform(rt_multi* m, const double obmat[4][4]);
+int rt_render_frame_multi(rt_multi* m, const rt_frame* f, int W, int H, double tan_half,
+                          uint8_t* screen);
+
 /* The frame loop of driver.c:28-203 as one pipelined call.  Frames first_frame,
  * first_frame + frame_step, ... (count of them) of the orbit of rt_driver_frame_setup(frame,
  * frames_per_turn): transform, render every row, place.  With bmp_pattern != NULL (a printf
@@ -270,7 +295,6 @@ int rt_mat_mult_pt(double P[3], const double m[4][4], const double Q[3]);
  * triangles and quads, four face formats, quads split (a,b,c)+(a,c,d), face normals
  * synthesised when the file has none, centre + scale to a 15-unit box.  The result is
  * structure-of-arrays in page-locked host memory when a GPU is present. */
-typedef struct rt_obj rt_obj;
 int rt_obj_load(const char* path, rt_obj** out);
 int rt_obj_free(rt_obj* o);
 typedef struct rt_obj_view {

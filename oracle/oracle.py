@@ -99,6 +99,10 @@ def lib() -> C.CDLL:
         L.orc_place_pixels.restype = None
         L.orc_place_pixels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_num_threads.restype = C.c_int
+        L.orc_dot3.restype = C.c_double
+        L.orc_dot3.argtypes = [dp, dp]
+        L.orc_norm3.restype = C.c_int
+        L.orc_norm3.argtypes = [dp, dp]
         L.orc_trace_rays.restype = None
         L.orc_trace_rays.argtypes = [C.POINTER(OrcScene), C.c_long, dp, dp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L

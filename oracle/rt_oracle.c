@@ -406,6 +406,11 @@ static int norm3(double res[3], const double a[3])
     return 1;
 }
 
+/* the two helpers above as the light model uses them, exported so that the tests can hold them
+ * against the reference's compiled M3d_dot_product / M3d_norm */
+double orc_dot3(const double a[3], const double b[3]) { return dot3(a, b); }
+int orc_norm3(double res[3], const double a[3]) { return norm3(res, a); }
+
 #define ORC_AMBIENT 0.2    /* light_model.c:13 */
 #define ORC_DIFFUSE 0.5    /* light_model.c:14 */
 #define ORC_SPECPOW 50.0   /* light_model.c:15 */

@@ -81,6 +81,8 @@ void orc_interpolate_normal(const OrcScene* sc, int tri, const double uv[2],
                             const double obinv[4][4], double normal[3]);
 void orc_get_rgb(const OrcTexture* tex, const OrcScene* sc, int tri, const double uv[2],
                  double rgb[3]);
+double orc_dot3(const double a[3], const double b[3]);        /* M3d_matrix_tools.c:238-242 */
+int orc_norm3(double res[3], const double a[3]);              /* M3d_matrix_tools.c:244-255 */
 uint8_t orc_quantize(double c);
 long orc_render_rows(const OrcScene* sc, const OrcFrame* f, int W, int H, double tan_half,
                      int y0, int y1, int ystep, int shade, int nthreads,

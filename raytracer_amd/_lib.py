@@ -115,6 +115,13 @@ SIGNATURES = {
     "rt_render_rows_part": (C.c_int, [C.c_void_p, C.POINTER(RtFrame), C.c_int, C.c_int, C.c_double,
                                       C.POINTER(RtRows)] + [C.c_void_p] * 4),
     "rt_place_rows_part": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(RtRows), C.c_void_p]),
+    "rt_multi_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, c_int_p]),
+    "rt_multi_destroy": (C.c_int, [C.c_void_p]),
+    "rt_multi_num_devices": (C.c_int, [C.c_void_p]),
+    "rt_multi_for_each_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_multi_set_obj": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_multi_transform": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_render_frame_multi": (C.c_int, [C.c_void_p, C.POINTER(RtFrame), C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "rt_render_sequence": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_char_p, C.POINTER(RtSequenceStats)]),
     "rt_sweep_config": (C.c_int, [c_int_p] * 4),

@@ -82,6 +82,7 @@ extern "C" int rt_init(int device_ordinal)
         RT_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
         g_scratch_ptr[device_ordinal] = ptr;
     }
+    (void)rt_device_cus();      // cached once, before any launcher can race for it
     g.device = device_ordinal;
     g.inited = true;
     return RT_OK;
@@ -122,8 +123,9 @@ extern "C" int rt_apex_sweep_config(int* tile_tris, int* primary_pixels_per_lane
 {
     if (tile_tris) *tile_tris = RT_TILE;
     // of the most recent primary sweep (the launcher shares less per lane on small images)
-    const int rpl = rt_g().last_raster_rpl > 0 ? rt_g().last_raster_rpl : RT_RASTER_RPL;
-    if (primary_chunks) *primary_chunks = rt_g().last_raster_chunks > 0 ? rt_g().last_raster_chunks : 1;
+    const int last_rpl = rt_g().last_raster_rpl.load(), last_chunks = rt_g().last_raster_chunks.load();
+    const int rpl = last_rpl > 0 ? last_rpl : RT_RASTER_RPL;
+    if (primary_chunks) *primary_chunks = last_chunks > 0 ? last_chunks : 1;
     if (primary_pixels_per_lane) *primary_pixels_per_lane = rpl;
     if (primary_flop_per_pair) *primary_flop_per_pair = rt_raster_flop_per_pair(rpl);
     if (shadow_rays_per_lane) *shadow_rays_per_lane = RT_APEX_RPL;
@@ -133,7 +135,8 @@ extern "C" int rt_apex_sweep_config(int* tile_tris, int* primary_pixels_per_lane
 
 extern "C" int rt_raster_sweep_mix(int* pixels_per_lane, int* fma, int* add, int* logic, int* compare)
 {
-    const int rpl = rt_g().last_raster_rpl > 0 ? rt_g().last_raster_rpl : RT_RASTER_RPL;
+    const int last_rpl = rt_g().last_raster_rpl.load();
+    const int rpl = last_rpl > 0 ? last_rpl : RT_RASTER_RPL;
     const RasterMix m = rt_raster_mix(rpl);
     if (pixels_per_lane) *pixels_per_lane = rpl;
     if (fma) *fma = m.fma;
@@ -170,12 +173,6 @@ void DevBuf::release()
     cap = 0;
 }
 
-#define RT_TRY(expr)                    \
-    do {                                \
-        int rt_rc_ = (expr);            \
-        if (rt_rc_ != RT_OK) return rt_rc_; \
-    } while (0)
-
 static int upload(DevBuf& b, const void* host, size_t bytes)
 {
     RT_TRY(b.reserve(bytes));
@@ -190,6 +187,7 @@ extern "C" int rt_scene_create(rt_scene** out)
     RT_ARG(out, "null output");
     RT_TRY(rt_ensure_init());
     *out = new rt_scene();
+    (void)hipGetDevice(&(*out)->device);
     return RT_OK;
 }
 
@@ -671,10 +669,10 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
 #endif
     a.tri_begin = 0; a.tri_end = sc->num_tris_padded;
     const uint64_t tests = (uint64_t)rt_raster_pairs(W, rows.rows, rpl, sc->num_tris_padded);
-    g.last_raster_rpl = rpl;
-    g.last_raster_chunks = chunks;
+    g.last_raster_rpl.store(rpl, std::memory_order_relaxed);
+    g.last_raster_chunks.store(chunks, std::memory_order_relaxed);
     RT_TRY(timed_sweep([&] { return rt_launch_sweep_raster(a, st); }, false, tests, nullptr));
-    g.prof.rays_primary += npix;
+    if (g.profiling) g.prof.rays_primary += npix;
 #ifdef RT_RASTER_CHECK_INTERVAL
     {
         unsigned long long t = 0;
@@ -863,6 +861,7 @@ static int resolve_rays(rt_scene* sc, const RayWorkspace& ws, int n, const doubl
                                   ws.counters, g.stream));
     RT_TRY(rt_launch_overflow_rays(es, S, E, ws.ovf, ws.counters, anyhit, hit, tuv, point, occ,
                                    ws.partials, g.stream));
+    if (!g.profiling) return RT_OK;        // (the record below is only kept while profiling)
     const uint64_t before = g.prof.rays_live;
     RT_TRY(fetch_counters(ws.counters, false));
     if (anyhit) g.prof.rays_shadow += g.prof.rays_live - before;
@@ -1098,8 +1097,10 @@ static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, doubl
     // frame constants
     DevBuf& frame_dev = sc->ws_frame;
     RT_TRY(frame_dev.reserve(sizeof(DevFrame)));
-    static DevFrame hf;     // static: outlives the async copy below
+    sc->frame_host.resize(sizeof(DevFrame));        // kept with the scene: outlives the async copy below
+    DevFrame& hf = *reinterpret_cast<DevFrame*>(sc->frame_host.data());
     hf.num_lights = L;
+    hf.pad = 0;
     memcpy(hf.obinv, f->obinv, sizeof hf.obinv);
     memcpy(hf.light_pos, f->light_in_eye_space, sizeof hf.light_pos);
     memcpy(hf.light_rgb, f->light_rgb, sizeof hf.light_rgb);

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,12 @@ void rt_set_error(const char* fmt, ...);
                          hipGetErrorString(rt_e_));                                     \
             return RT_E_HIP;                                                            \
         }                                                                               \
+    } while (0)
+
+#define RT_TRY(expr)                        \
+    do {                                    \
+        int rt_rc_ = (expr);                \
+        if (rt_rc_ != RT_OK) return rt_rc_; \
     } while (0)
 
 #define RT_ARG(cond, msg)                                                               \
@@ -115,6 +122,8 @@ struct rt_scene {
     DevBuf tex_desc;            // DevTexture[num_tex]
     std::vector<DevBuf> tex_data;
     bool has_tex_idx = false;
+    int device = 0;             // HIP device the scene's buffers live on (current at rt_scene_create)
+    std::vector<unsigned char> frame_host;      // staging copy of the frame constants
     // host-side extremes of the index arrays, checked against the tables before a render
     int mtl_max = -1;           // largest mtl[] entry
     int map_max = -1;           // largest map_Ka/Kd/Ks entry of any material (-1: no textured material)
@@ -168,13 +177,14 @@ struct RtGlobal {
     int device = -1;
     hipStream_t stream = nullptr;
     bool profiling = false;
-    int last_raster_rpl = 0;    // pixels per lane of the most recent primary sweep
-    int last_raster_chunks = 0; // and its triangle chunks
+    std::atomic<int> last_raster_rpl{0};    // pixels per lane of the most recent primary sweep
+    std::atomic<int> last_raster_chunks{0}; // and its triangle chunks
     rt_profile prof{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 RtGlobal& rt_g();
 int rt_ensure_init();
+int rt_device_cus();        // compute units of the device (cached; every device of a node is alike)
 
 // ---------------------------------------------------------------- launchers (defined per .hip file)
 // rt_transform.hip

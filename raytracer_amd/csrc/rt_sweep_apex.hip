@@ -657,7 +657,7 @@ int check_common(const SweepArgs& a)
 
 }  // namespace
 
-static int device_cus()
+int rt_device_cus()
 {
     static int cus = 0;         // the device query is slow: once per process
     if (cus == 0) {
@@ -684,7 +684,7 @@ static int device_cus()
 // small inputs).
 void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks, int* waves_x)
 {
-    const long slots = 5L * device_cus();           // resident workgroups
+    const long slots = 5L * rt_device_cus();           // resident workgroups
     int max_chunks = tiles / 8;
     if (max_chunks < 1) max_chunks = 1;
     // (the chunks of a pixel share its candidate list, so their number costs no memory)
@@ -803,8 +803,8 @@ static int apex_max_chunks(int tiles)
 static int apex_rays_per_lane(long n, int max_chunks)
 {
     int r = RT_APEX_RPL;
-    if (r >= 8 && (n / (RT_WG * r)) * max_chunks < 6L * device_cus()) r = 4;
-    while (r > 1 && r <= 4 && 2 * ((n + RT_WG * r - 1) / (RT_WG * r)) * max_chunks < 5L * device_cus()) r /= 2;
+    if (r >= 8 && (n / (RT_WG * r)) * max_chunks < 6L * rt_device_cus()) r = 4;
+    while (r > 1 && r <= 4 && 2 * ((n + RT_WG * r - 1) / (RT_WG * r)) * max_chunks < 5L * rt_device_cus()) r /= 2;
     return r;
 }
 
@@ -812,7 +812,7 @@ static int apex_rays_per_lane(long n, int max_chunks)
 // about RT_APEX_ROUNDS rounds of work.
 static int apex_chunks(long wgs, int max_chunks)
 {
-    const long slots = 5L * device_cus();
+    const long slots = 5L * rt_device_cus();
     long c = (RT_APEX_ROUNDS * slots + wgs - 1) / wgs;
     if (c > max_chunks) c = max_chunks;
     return c < 1 ? 1 : (int)c;

@@ -151,10 +151,24 @@ class Scene:
         if mesh is not None:
             self.set_mesh(mesh)
 
+    @classmethod
+    def adopt(cls, handle, device: int = 0) -> "Scene":
+        """A Scene over an rt_scene handle that someone else owns (the scenes of a MultiScene)."""
+        import torch
+
+        self = cls.__new__(cls)
+        self.torch = torch
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device)
+        self.h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+        self.mesh = None
+        self.owned = False
+        return self
+
     def close(self):
-        if self.h:
+        if self.h and getattr(self, "owned", True):
             self.lib.rt_scene_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -293,6 +307,61 @@ class Scene:
             check(self.lib.rt_place_rows_part(rgb8.data_ptr(), W, H, C.byref(rows_set), screen.data_ptr()),
                   "rt_place_rows_part")
         return screen
+
+
+class MultiScene:
+    """One frame on several GPUs from this process (rt_multi in include/rt_amd.h): the mesh on
+    every device, interleaved row parts, the rows gathered to the first device over RCCL."""
+
+    def __init__(self, mesh: Mesh, devices):
+        import torch
+
+        self.torch = torch
+        self.lib = _lib.load()
+        devs = np.ascontiguousarray(list(devices), np.int32)
+        h = C.c_void_p()
+        check(self.lib.rt_multi_create(C.byref(h), len(devs), _ip(devs)), "rt_multi_create")
+        self.h = h
+        self.devices = [int(d) for d in devs]
+        errors = []
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+        def upload(scene, part, _user):
+            try:
+                Scene.adopt(scene, self.devices[part]).set_mesh(mesh)
+                return 0
+            except Exception as e:          # an exception must not cross the C frame
+                errors.append(e)
+                return -1
+
+        rc = self.lib.rt_multi_for_each_scene(self.h, upload, None)
+        if errors:
+            raise errors[0]
+        check(rc, "rt_multi_for_each_scene")
+
+    def transform(self, m) -> None:
+        m = _mat(m)
+        check(self.lib.rt_multi_transform(self.h, m.ctypes.data), "rt_multi_transform")
+
+    def render_frame(self, frame: RtFrame, W: int, H: int, tan_half: float, screen=None):
+        """The placed W x H x 3 picture on the first device."""
+        t = self.torch
+        if screen is None:
+            screen = t.empty((H, W, 3), dtype=t.uint8, device=t.device("cuda", self.devices[0]))
+        check(self.lib.rt_render_frame_multi(self.h, C.byref(frame), W, H, float(tan_half), screen.data_ptr()),
+              "rt_render_frame_multi")
+        return screen
+
+    def close(self):
+        if self.h:
+            self.lib.rt_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def profile_enable(on: bool = True) -> None:

@@ -1,11 +1,15 @@
 """rt_render_sequence: the pipelined frame loop writes the same pictures as the frame-by-frame
-calls, for a plain run and for a strided (frame-parallel) one."""
+calls, for a plain run and for a strided (frame-parallel) one, and the pictures it writes are
+the oracle's (driver.c:28-203 restated on the CPU: frame set-up, transform, pixel loop, 8-bit
+store, placement)."""
 import os
+import struct
 
 import numpy as np
 import pytest
 import torch
 
+from oracle import oracle as O
 from raytracer_amd import kernel, scenes
 from conftest import TAN_HALF
 
@@ -37,6 +41,44 @@ def test_sequence_writes_the_frames_of_the_single_frame_path(tmp_path, first, co
         assert len(a) == 122 + W * H * 4 and a == b, f
     # pictures differ from frame to frame (the orbit moves)
     assert open(tmp_path / f"pic{frames[0]:04d}.bmp", "rb").read() != open(tmp_path / f"pic{frames[1]:04d}.bmp", "rb").read()
+    sc.close()
+
+
+def _decode_bmp(path, W, H):
+    """The 32-bit BMP of graphic_tools.c:19-23,115-121 -> H x W x 3 RGB, top row first."""
+    raw = open(path, "rb").read()
+    off = struct.unpack_from("<I", raw, 10)[0]
+    w, h = struct.unpack_from("<ii", raw, 18)
+    assert (w, h) == (W, H) and struct.unpack_from("<H", raw, 28)[0] == 32
+    px = np.frombuffer(raw, dtype=np.uint8, offset=off).reshape(H, W, 4)[::-1]      # bottom-up rows, B G R A
+    assert np.all(px[..., 3] == 255)
+    return px[..., 2::-1]
+
+
+def test_sequence_pictures_are_the_oracles(tmp_path):
+    """Frames of the written sequence against the CPU oracle's whole frame loop: the oracle's own
+    frame set-up (pinned to the reference's M3d code), its transform, pixel loop and placement."""
+    W, H, turn = 128, 96, 24
+    mesh = scenes.with_materials(scenes.torus(1200))
+    sc = kernel.Scene(mesh)
+    frames = [1, 6, 11, 16, 21]
+    st = sc.render_sequence(frames[0], len(frames), W, H, TAN_HALF, frames_per_turn=turn, frame_step=5,
+                            bmp_pattern=str(tmp_path / "pic%04d.bmp"))
+    assert st.frames == len(frames)
+    lit = 0
+    for f in frames:
+        got = _decode_bmp(tmp_path / f"pic{f:04d}.bmp", W, H)
+        ofr = O.frame_setup(f, turn)                                  # driver.c:34-107
+        X, Y, Z = O.transform(mesh, O.arr4(ofr.obmat))                # driver.c:110
+        ref = O.render_rows(O.Scene(mesh, X, Y, Z), ofr, W, H, TAN_HALF)      # driver.c:126-185
+        want = O.place_pixels(ref["rgb8"])                            # driver.c:186-190
+        assert (ref["hit"] >= 0).sum() > 0.05 * W * H
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 1, f"frame {f}: a channel differs by {d.max()}"     # 1/255 per channel
+        assert (d > 0).mean() < 1e-3
+        assert np.all(got[0] == 0)                                    # row 0 keeps the clear colour
+        lit += len(np.unique(want.reshape(-1, 3), axis=0))
+    assert lit > 50 * len(frames)                                     # shaded pictures, not flat ones
     sc.close()
 
 

@@ -41,6 +41,8 @@ def test_no_device_fails_loudly():
     assert b"no HIP device" in lib.rt_last_error()
     h = C.c_void_p()
     assert lib.rt_scene_create(C.byref(h)) == -5     # nothing falls back to the CPU
+    assert lib.rt_multi_create(C.byref(h), 2, None) == -5 and not h.value
+    assert lib.rt_multi_num_devices(None) == 0 and lib.rt_multi_destroy(None) == 0
 
 
 def test_reference_struct_layout():

@@ -135,3 +135,55 @@ def test_cross_dot_norm_twins():
         R.M3d_norm(O.d(n), O.d(a))
         mag = np.sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2])
         assert np.array_equal(n, a / mag)
+
+
+def test_oracle_dot_and_norm_are_the_references():
+    """The oracle's own C helpers behind Light_Model (dot3, norm3 in rt_oracle.c), not a numpy
+    restatement of them, against the compiled M3d_dot_product / M3d_norm: bit for bit, zero
+    vector included."""
+    rng = np.random.default_rng(17)
+    L = O.lib()
+    vecs = [rng.normal(size=3) * 10.0 ** rng.integers(-8, 8) for _ in range(2000)] + [np.zeros(3), np.array([0.0, -0.0, 0.0])]
+    for k, a in enumerate(vecs):
+        b = vecs[(k * 7 + 3) % len(vecs)]
+        assert L.orc_dot3(O.d(a), O.d(b)) == R.M3d_dot_product(O.d(a), O.d(b))
+        mine, ref = np.full(3, 7.0), np.full(3, 7.0)
+        assert L.orc_norm3(O.d(mine), O.d(a)) == R.M3d_norm(O.d(ref), O.d(a))
+        assert np.array_equal(mine, ref)          # untouched (7, 7, 7) when the vector is zero
+
+
+def test_face_normals_of_both_loaders_are_m3d_x_product(tmp_path):
+    """Faces without vn get one un-normalised normal AB x AC from the raw coordinates
+    (obj_reader.c:51-82 through M3d_x_product): the product's loader (rt_obj_load) and the
+    oracle's (obj_oracle.load) against the compiled reference's M3d_x_product."""
+    import ctypes as C
+    from oracle import obj_oracle
+    from raytracer_amd import _lib
+    rng = np.random.default_rng(23)
+    nv, nf = 60, 40
+    P = rng.normal(size=(nv, 3)) * 3.0
+    faces = [rng.choice(nv, size=3, replace=False) + 1 for _ in range(nf)]
+    path = tmp_path / "soup.obj"
+    # repr() round-trips a double exactly through the loaders' decimal parsing
+    path.write_text("".join(f"v {repr(float(p[0]))} {repr(float(p[1]))} {repr(float(p[2]))}\n" for p in P) +
+                    "".join(f"f {f[0]} {f[1]} {f[2]}\n" for f in faces))
+    want = []
+    for f in faces:
+        A, B, Cc = (P[i - 1] for i in f)
+        AB, AC, r = np.ascontiguousarray(B - A), np.ascontiguousarray(Cc - A), np.zeros(3)
+        R.M3d_x_product(O.d(r), O.d(AB), O.d(AC))
+        want.append(r)
+    want = np.array(want)
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.rt_obj_load(str(path).encode(), C.byref(h)) == 0
+    v = _lib.RtObjView()
+    assert lib.rt_obj_get(h, C.byref(v)) == 0
+    assert v.num_vn == nf and v.num_tris == nf
+    got = np.stack([np.ctypeslib.as_array(getattr(v, k), shape=(nf + 1,))[1:] for k in ("xn", "yn", "zn")], 1).copy()
+    An = np.ctypeslib.as_array(v.An, shape=(nf,)).copy()
+    lib.rt_obj_free(h)
+    assert np.array_equal(An, np.arange(1, nf + 1))
+    assert np.array_equal(got, want)
+    om = obj_oracle.load(str(path))
+    assert np.array_equal(np.stack([om["xn"][1:], om["yn"][1:], om["zn"][1:]], 1), want)
