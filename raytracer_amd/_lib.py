@@ -139,6 +139,8 @@ SIGNATURES = {
     "rt_obj_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "rt_obj_free": (C.c_int, [C.c_void_p]),
     "rt_obj_get": (C.c_int, [C.c_void_p, C.POINTER(RtObjView)]),
+    "rt_obj_num_textures": (C.c_int, [C.c_void_p]),
+    "rt_obj_texture": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p, C.POINTER(C.c_void_p)]),
     "rt_scene_set_obj": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_save_bmp": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
 }

@@ -23,5 +23,5 @@ for src in rt_sweep.hip rt_sweep_apex.hip rt_sort.hip rt_exact.hip rt_transform.
   fi
   objs+=("$obj")
 done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}" -ldl -lpthread
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}" -ldl -lpthread -lz
 echo "built $out"

@@ -22,9 +22,14 @@
 // index itself is stored here.
 //
 // Image maps: the reference decodes them with SDL_image (:352-381) and keeps a NULL map when
-// decoding fails.  This loader decodes binary PPM (P6) and uncompressed 24/32-bit BMP; any
-// other format is treated like a failed IMG_Load (the material keeps its constant colour).
+// decoding fails.  This loader decodes PNG (every colour type and bit depth, interlaced or not,
+// through zlib; what the texture fetch of graphic_tools.c:161-197 sees is the pixel's RGB as
+// SDL_GetRGB reports it: palette entries resolved, grey replicated, alpha ignored, 16-bit
+// samples cut to their high byte), binary PPM (P6) and uncompressed 24/32-bit BMP.  Any other
+// format (JPEG among them) is treated like a failed IMG_Load: the material keeps its constant
+// colour.
 #include <hip/hip_runtime_api.h>
+#include <zlib.h>
 
 #include <cctype>
 #include <cstdint>
@@ -161,6 +166,133 @@ bool load_bmp(const std::string& d, Image& im)
     return true;
 }
 
+// PNG (ISO/IEC 15948): signature, IHDR, optional PLTE, IDAT stream (zlib), IEND.  Scanlines are
+// filtered per byte (None, Sub, Up, Average, Paeth); Adam7 interlacing stores seven reduced
+// images one after the other.  Chunk CRCs are not verified (zlib checks the pixel stream's
+// Adler-32).
+bool load_png(const std::string& d, Image& im)
+{
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (d.size() < 8 + 25 || memcmp(d.data(), sig, 8) != 0) return false;
+    const uint8_t* p = (const uint8_t*)d.data();
+    auto be32 = [&](size_t o) {
+        return (uint32_t)p[o] << 24 | (uint32_t)p[o + 1] << 16 | (uint32_t)p[o + 2] << 8 | (uint32_t)p[o + 3];
+    };
+    uint32_t W = 0, H = 0;
+    int depth = 0, ctype = -1, interlace = 0;
+    std::vector<uint8_t> plte, idat;
+    bool have_ihdr = false, done = false;
+    for (size_t o = 8; !done && o + 12 <= d.size();) {
+        const uint32_t len = be32(o);
+        if (len > d.size() - o - 12) return false;
+        const char* type = d.data() + o + 4;
+        const uint8_t* body = p + o + 8;
+        if (!memcmp(type, "IHDR", 4)) {
+            if (len != 13 || have_ihdr) return false;
+            W = be32(o + 8); H = be32(o + 12);
+            depth = body[8]; ctype = body[9]; interlace = body[12];
+            if (body[10] != 0 || body[11] != 0 || interlace > 1) return false;
+            have_ihdr = true;
+        } else if (!memcmp(type, "PLTE", 4)) {
+            plte.assign(body, body + len);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            done = true;
+        }
+        o += 12 + (size_t)len;
+    }
+    if (!have_ihdr || W == 0 || H == 0 || W > 32768 || H > 32768 || idat.empty()) return false;
+    int channels;
+    switch (ctype) {
+    case 0: channels = 1; break;        // grey
+    case 2: channels = 3; break;        // RGB
+    case 3: channels = 1; break;        // palette index
+    case 4: channels = 2; break;        // grey + alpha
+    case 6: channels = 4; break;        // RGB + alpha
+    default: return false;
+    }
+    const bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
+                          (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
+                          ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
+    if (!depth_ok || (ctype == 3 && (plte.empty() || plte.size() % 3 != 0))) return false;
+    const int bits_pp = channels * depth;                   // bits per pixel
+    const size_t bpp = (size_t)(bits_pp + 7) / 8;           // filter distance in bytes (>= 1)
+    auto row_bytes = [&](uint32_t w) { return ((size_t)w * bits_pp + 7) / 8; };
+    // the passes: (x0, y0, dx, dy); one pass when not interlaced
+    static const int adam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const int whole[1][4] = {{0, 0, 1, 1}};
+    const int (*pass)[4] = interlace ? adam7 : whole;
+    const int npass = interlace ? 7 : 1;
+    size_t raw_size = 0;
+    for (int k = 0; k < npass; ++k) {
+        const uint32_t pw = (W - pass[k][0] + pass[k][2] - 1) / pass[k][2], ph = (H - pass[k][1] + pass[k][3] - 1) / pass[k][3];
+        if (W <= (uint32_t)pass[k][0] || H <= (uint32_t)pass[k][1] || pw == 0 || ph == 0) continue;
+        raw_size += (row_bytes(pw) + 1) * ph;
+    }
+    std::vector<uint8_t> raw(raw_size);
+    uLongf got = (uLongf)raw_size;
+    if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw_size) return false;
+    im.w = (int)W; im.h = (int)H;
+    im.rgb.assign((size_t)W * H * 3, 0);
+    size_t at = 0;
+    std::vector<uint8_t> prev, cur;
+    for (int k = 0; k < npass; ++k) {
+        if (W <= (uint32_t)pass[k][0] || H <= (uint32_t)pass[k][1]) continue;
+        const uint32_t pw = (W - pass[k][0] + pass[k][2] - 1) / pass[k][2], ph = (H - pass[k][1] + pass[k][3] - 1) / pass[k][3];
+        if (pw == 0 || ph == 0) continue;
+        const size_t rb = row_bytes(pw);
+        prev.assign(rb, 0);
+        cur.resize(rb);
+        for (uint32_t y = 0; y < ph; ++y) {
+            const int filter = raw[at++];
+            const uint8_t* src = &raw[at];
+            at += rb;
+            for (size_t i = 0; i < rb; ++i) {
+                const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+                int pred;
+                switch (filter) {
+                case 0: pred = 0; break;
+                case 1: pred = a; break;
+                case 2: pred = b; break;
+                case 3: pred = (a + b) / 2; break;
+                case 4: {
+                    const int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c);
+                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                    break;
+                }
+                default: return false;
+                }
+                cur[i] = (uint8_t)(src[i] + pred);
+            }
+            // samples of the row -> 8-bit RGB
+            auto sample = [&](uint32_t x, int ch) -> int {          // raw sample value
+                const size_t bit = ((size_t)x * channels + ch) * depth;
+                if (depth == 8) return cur[bit / 8];
+                if (depth == 16) return cur[bit / 8];               // high byte (SDL_image strips 16 -> 8)
+                return (cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1);
+            };
+            const uint32_t oy = pass[k][1] + y * pass[k][3];
+            for (uint32_t x = 0; x < pw; ++x) {
+                uint8_t* o = &im.rgb[((size_t)oy * W + pass[k][0] + (size_t)x * pass[k][2]) * 3];
+                if (ctype == 3) {
+                    const size_t e = (size_t)sample(x, 0) * 3;
+                    if (e + 2 < plte.size()) { o[0] = plte[e]; o[1] = plte[e + 1]; o[2] = plte[e + 2]; }
+                } else if (ctype == 0 || ctype == 4) {
+                    int g = sample(x, 0);
+                    if (depth < 8) g = g * 255 / ((1 << depth) - 1);        // full-range scaling of 1/2/4-bit grey
+                    o[0] = o[1] = o[2] = (uint8_t)g;
+                } else {
+                    o[0] = (uint8_t)sample(x, 0); o[1] = (uint8_t)sample(x, 1); o[2] = (uint8_t)sample(x, 2);
+                }
+            }
+            prev.swap(cur);
+            cur.resize(rb);
+        }
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------- parsed object
 struct MaterialRec {
     std::string name;
@@ -288,7 +420,7 @@ struct Builder {
     {
         std::string data;
         Image im;
-        if (!read_file(dir + name, data) || !(load_ppm(data, im) || load_bmp(data, im))) {
+        if (!read_file(dir + name, data) || !(load_png(data, im) || load_ppm(data, im) || load_bmp(data, im))) {
             fprintf(stderr, "rt_obj: cannot decode image map %s%s (kept as a constant colour)\n",
                     dir.c_str(), name.c_str());
             return -1;                                       // IMG_Load failed, :360-363
@@ -504,6 +636,21 @@ extern "C" int rt_obj_get(const rt_obj* o, rt_obj_view* out)
         return RT_E_ARG;
     }
     *out = o->view;
+    return RT_OK;
+}
+
+extern "C" int rt_obj_num_textures(const rt_obj* o) { return o ? (int)o->textures.size() : 0; }
+
+extern "C" int rt_obj_texture(const rt_obj* o, int index, int* w, int* h, const uint8_t** rgb)
+{
+    if (!o || index < 0 || index >= (int)o->textures.size()) {
+        rt_set_error("rt_obj_texture: no texture %d", index);
+        return RT_E_ARG;
+    }
+    const Image& im = o->textures[(size_t)index];
+    if (w) *w = im.w;
+    if (h) *h = im.h;
+    if (rgb) *rgb = im.rgb.data();
     return RT_OK;
 }
 
