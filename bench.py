@@ -151,6 +151,13 @@ def main() -> None:
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: functional rehearsal of the multi-rank path with several ranks on one "
                          "GPU (the gather goes through host copies); not a measurement")
+    ap.add_argument("--single-process", action="store_true",
+                    help="without a launcher: this one process drives --gpus devices through "
+                         "rt_render_frame_multi (one host thread per device inside the library, rows to "
+                         "device 0 over RCCL send/recv) instead of one process per GPU")
+    ap.add_argument("--devices", default=None,
+                    help="with --single-process: comma-separated HIP ordinals (default 0..gpus-1; a device "
+                         "may be named twice for a rehearsal on one GPU)")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed steps rank 0 renders the whole frame alone and compares it "
                          "with the assembled screen")
@@ -163,7 +170,12 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    single = args.single_process
+    devices = ([int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))) if single else None
+    if single and (world != 1 or args.workload.endswith("_seq_4k")):
+        print("bench.py: --single-process runs without a launcher and renders single frames", file=sys.stderr)
+        sys.exit(2)
+    if not single and world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
                   file=sys.stderr)
@@ -191,7 +203,9 @@ def main() -> None:
     obmats = [kernel.frame_matrix(f, "obmat") for f in frames]
     frame = frames[0]
     step_no = [0]
+    profiled = [False]        # the profiled frame of a --single-process run goes through the plain scene
     sc = kernel.Scene(mesh, device=local_rank)
+    ms = kernel.MultiScene(mesh, devices) if single else None
     # A frame sequence is split by frames: rank r renders frames r, r + world, ... whole, and
     # nothing is exchanged (driver.c:196-199 writes one picture per frame; so would every rank).
     frame_parallel = sequence and world > 1
@@ -209,6 +223,10 @@ def main() -> None:
     def step():
         k = (step_no[0] * world + rank if frame_parallel else step_no[0]) % len(frames)
         step_no[0] += 1
+        if ms is not None and not profiled[0]:
+            ms.transform(obmats[k])
+            ms.render_frame(frames[k], W, H, TAN_HALF, screen=screen)
+            return
         sc.transform(obmats[k])                   # driver.c:110 on the device-resident mesh
         sc.render_rows(frames[k], W, H, TAN_HALF, want=("hit", "rgb8"), rows_set=my_rows,
                        out={"hit": out["hit"], "rgb8": out["rgb8"][:rows]})
@@ -251,6 +269,9 @@ def main() -> None:
     kernel.profile_enable(True)
     kernel.profile_reset()
     step_no[0] -= 1 if not sequence else 0        # the same frame again, except in a sequence
+    profiled[0] = True
+    if ms is not None:
+        single_screen = screen.clone()
     step()
     fence()
     prof = kernel.profile_get()
@@ -299,7 +320,7 @@ def main() -> None:
             "metric": "Mrays/s and ray-tri tests/s (% fp32 peak) at 1/2/4/8 MI355X vs host-CPU ref",
             "value": (rays_p + rays_s) / (wall / steps) / 1e6,
             "unit": "Mrays/s",
-            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "n_gpus": len(devices) if single else world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": wall / steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak" if frame_parallel else "strong",
@@ -311,7 +332,9 @@ def main() -> None:
                        "sharding": f"{world} ranks, one whole frame each per step (frames rank, rank + {world}, ...), no exchange"
                        if frame_parallel else (f"{world} interleaved row parts (16-row blocks), "
                                     f"{'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} gather to rank 0")
-                       if world > 1 else "single GPU"},
+                       if world > 1 else (f"one process, devices {devices}: interleaved row parts, rt_render_frame_multi "
+                                          "(one host thread per device, rows to the first device over RCCL send/recv)"
+                                          if single else "single GPU")},
             "frames_per_s": steps * (world if frame_parallel else 1) / wall,
             "primary_mrays_per_s": rays_p / (wall / steps) / 1e6,
             "rays_per_frame": {"primary": rays_p, "shadow": rays_s},
@@ -371,7 +394,10 @@ def main() -> None:
                 },
             },
         }
-        if args.verify:
+        if single:
+            # the picture the devices assembled against the profiled single-scene render of the same frame
+            res["verify"] = {"screen_equals_single_rank_render": bool(torch.equal(single_screen, screen))}
+        if args.verify and not single:
             k = ((step_no[0] - 1) * world + rank if frame_parallel else step_no[0] - 1) % len(frames)
             sc.transform(obmats[k])
             alone = sc.render_rows(frames[k], W, H, TAN_HALF, want=("rgb8",))["rgb8"]

@@ -49,3 +49,13 @@ def test_frame_sequence_is_split_by_frames():
     assert d["verify"]["screen_equals_single_rank_render"] is True
     assert d["rays_per_frame"]["primary"] == 2 * 3840 * 2160          # two frames per step
     assert abs(d["frames_per_s"] * d["ms_per_step"] * 1e-3 - 2.0) < 1e-6
+
+
+def test_single_process_mode_drives_the_devices_itself():
+    """bench.py --single-process: no launcher, rt_render_frame_multi over the named devices (here
+    the one GPU named three times: threads, parts, placement; rows by peer copies)."""
+    d = _bench([sys.executable, "bench.py", "--gpus", "3", "--single-process", "--devices", "0,0,0", "--steps", "2",
+                "--warmup", "1", "--workload", "teapot_class_480p", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 3 and d["verify"]["screen_equals_single_rank_render"] is True
+    assert d["rays_per_frame"]["primary"] == 640 * 480 and "rt_render_frame_multi" in d["config"]["sharding"]
+    assert d["roofline"]["anyhit"]["tests_per_frame"] > 0
