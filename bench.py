@@ -333,7 +333,7 @@ def main() -> None:
                        if frame_parallel else (f"{world} interleaved row parts (16-row blocks), "
                                     f"{'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} gather to rank 0")
                        if world > 1 else (f"one process, devices {devices}: interleaved row parts, rt_render_frame_multi "
-                                          "(one host thread per device, rows to the first device over RCCL send/recv)"
+                                          "(one host thread per device, rows to the first device over RCCL send/recv; peer copies where a device is named twice)"
                                           if single else "single GPU")},
             "frames_per_s": steps * (world if frame_parallel else 1) / wall,
             "primary_mrays_per_s": rays_p / (wall / steps) / 1e6,

@@ -59,3 +59,14 @@ def test_bad_row_sets_are_rejected(bad):
     r = kernel.rows_part(64, kw["parts"], kw["part"], kw["block"])
     assert _lib.load().rt_rows_count(C.byref(r)) < 0
     assert b"row set" in _lib.load().rt_last_error()
+
+
+def test_rt_band_gives_the_first_ranks_the_extra_rows():
+    """rt_band: contiguous bands of H // n rows, the first H % n ranks one row more (a C caller
+    sizes its buffers from this rule)."""
+    for H, n in ((2160, 8), (1080, 7), (10, 3), (5, 8), (480, 1)):
+        bands = [kernel.band(H, n, r) for r in range(n)]
+        assert bands[0][0] == 0 and bands[-1][1] == H
+        assert all(bands[r][1] == bands[r + 1][0] for r in range(n - 1))
+        sizes = [y1 - y0 for y0, y1 in bands]
+        assert sizes == [H // n + (1 if r < H % n else 0) for r in range(n)]
