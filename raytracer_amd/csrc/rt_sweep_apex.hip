@@ -674,14 +674,14 @@ int rt_device_cus()
 // Launch shape of the pixel-grid sweep.  The most sharing per lane (RT_RASTER_RPL pixels) is
 // kept as long as the image is wide enough.  Every workgroup of a launch takes the same time,
 // so the machine drains in rounds and the last, partly filled round is wasted time; cutting the
-// triangle range into chunks that run as separate workgroups (with candidate lists of their
-// own) makes the rounds shorter and fills small bands.  Measured on the 1 M-triangle soup:
-// 8 chunks instead of 1 take 6 % off a 3840x2160 sweep and 33 % off a 3840x270 one, at the
-// price of three times as many candidates for the exact pass (less pruning across chunks).
-// A chunk keeps at least 8 tiles; a mesh too small to fill the machine that way gives up
+// triangle range into chunks that run as separate workgroups makes the rounds shorter and fills
+// small bands.  The chunks of a pixel share its candidate list and closest-hit bound (atomics in
+// the rare path), so their number costs neither memory nor pruning: about 24 rounds of
+// workgroups, 61 chunks for a 3840x2160 frame of a million triangles, some 480 for an eighth of
+// it.  A chunk keeps at least 8 tiles; a mesh too small to fill the machine that way gives up
 // pixels per lane instead.  RT_AMD_RASTER_FORCE="<pixels per lane>,<chunks>[,<waves side by
-// side>]" overrides the choice (read at every call: tests use it to run every kernel shape on
-// small inputs).
+// side, 0 = dealt row by row>]" overrides the choice (read at every call: tests use it to run
+// every kernel shape on small inputs).
 void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks, int* waves_x)
 {
     const long slots = 5L * rt_device_cus();           // resident workgroups
