@@ -310,9 +310,10 @@ typedef struct rt_obj_view {
 int rt_obj_get(const rt_obj* o, rt_obj_view* out);
 /* The image maps the .mtl files named (map_Ka / map_Kd / map_Ks, obj_reader.c:352-381), decoded
  * to tightly packed 8-bit RGB, top row first: PNG (all colour types and bit depths, interlaced
- * or not), binary PPM, uncompressed 24/32-bit BMP.  A file in any other format (JPEG) or one that
- * fails to decode leaves the material's map at -1, as a failed IMG_Load leaves it NULL.  The
- * pixels belong to the rt_obj. */
+ * or not), baseline JPEG (8-bit, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0, decoded like libjpeg does by
+ * default), binary PPM, uncompressed 24/32-bit BMP.  A file in any other format (progressive
+ * JPEG, ...) or one that fails to decode leaves the material's map at -1, as a failed IMG_Load
+ * leaves it NULL.  The pixels belong to the rt_obj. */
 int rt_obj_num_textures(const rt_obj* o);
 int rt_obj_texture(const rt_obj* o, int index, int* w, int* h, const uint8_t** rgb);
 int rt_scene_set_obj(rt_scene* sc, const rt_obj* o);

@@ -25,9 +25,9 @@
 // decoding fails.  This loader decodes PNG (every colour type and bit depth, interlaced or not,
 // through zlib; what the texture fetch of graphic_tools.c:161-197 sees is the pixel's RGB as
 // SDL_GetRGB reports it: palette entries resolved, grey replicated, alpha ignored, 16-bit
-// samples cut to their high byte), binary PPM (P6) and uncompressed 24/32-bit BMP.  Any other
-// format (JPEG among them) is treated like a failed IMG_Load: the material keeps its constant
-// colour.
+// samples cut to their high byte), baseline JPEG (libjpeg's default decoding stages, see
+// JpegDecoder), binary PPM (P6) and uncompressed 24/32-bit BMP.  Any other format (progressive
+// JPEG among them) is treated like a failed IMG_Load: the material keeps its constant colour.
 #include <hip/hip_runtime_api.h>
 #include <zlib.h>
 
@@ -293,6 +293,349 @@ bool load_png(const std::string& d, Image& im)
     return true;
 }
 
+// Baseline / extended-sequential JPEG (ITU T.81), 8 bits per sample, one or three components in
+// one interleaved scan, chroma subsampled 1x1, 2x1 or 2x2, restart intervals.  SDL_image decodes
+// JPEG through libjpeg with its defaults, so the same three stages are used here so that the
+// texels agree with what the reference's texture fetch would see: the accurate integer inverse
+// DCT (13-bit constants, two passes), "fancy" triangle-filter chroma upsampling, and the 16-bit
+// fixed-point YCbCr -> RGB tables.  Progressive, arithmetic-coded, 12-bit, CMYK and other
+// subsamplings are refused (the map then behaves like a failed IMG_Load).
+struct JpegDecoder {
+    const uint8_t* d;
+    size_t n, pos = 0;
+    struct Huff {
+        bool present = false;
+        uint8_t vals[256];
+        int mincode[17], maxcode[18], valptr[17];
+    } dc[4], ac[4];
+    uint16_t qt[4][64];
+    bool qt_present[4] = {false, false, false, false};
+    struct Comp {
+        int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0;
+        int stride = 0, rows = 0;       // padded plane
+        int dw = 0, dh = 0;             // real (downsampled) size
+        std::vector<uint8_t> plane;
+    } comp[3];
+    int W = 0, H = 0, ncomp = 0, hmax = 1, vmax = 1, restart = 0;
+    bool adobe_rgb = false;
+    uint32_t bitbuf = 0;
+    int bitcnt = 0;
+    bool bad = false;
+
+    int u8() { return pos < n ? d[pos++] : (bad = true, 0); }
+    int u16() { const int a = u8(); return a << 8 | u8(); }
+
+    void fill()
+    {
+        while (bitcnt <= 24) {
+            int b = 0;
+            if (pos >= n) bad = true;           // the data ends inside the scan (no EOI marker): refuse
+            if (pos < n) {
+                b = d[pos];
+                if (b == 0xFF) {
+                    const int m = pos + 1 < n ? d[pos + 1] : 0xD9;
+                    if (m == 0) pos += 2;           // stuffed zero
+                    else b = 0;                     // a marker: feed zeros, leave it in place
+                } else {
+                    ++pos;
+                }
+            }
+            bitbuf |= (uint32_t)b << (24 - bitcnt);
+            bitcnt += 8;
+        }
+    }
+    int bits(int k)
+    {
+        if (k == 0) return 0;
+        fill();
+        const int v = (int)(bitbuf >> (32 - k));
+        bitbuf <<= k;
+        bitcnt -= k;
+        return v;
+    }
+    int decode(const Huff& h)
+    {
+        int code = 0;
+        for (int len = 1; len <= 16; ++len) {
+            code = code << 1 | bits(1);
+            if (h.maxcode[len] >= 0 && code <= h.maxcode[len] && code >= h.mincode[len])
+                return h.vals[h.valptr[len] + code - h.mincode[len]];
+        }
+        bad = true;
+        return 0;
+    }
+    static int extend(int v, int s) { return s && v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+
+    bool build(Huff& h, const uint8_t counts[17], const uint8_t* vals, int nvals)
+    {
+        int code = 0, k = 0;
+        for (int len = 1; len <= 16; ++len) {
+            h.valptr[len] = k;
+            h.mincode[len] = code;
+            code += counts[len];
+            k += counts[len];
+            h.maxcode[len] = counts[len] ? code - 1 : -1;
+            code <<= 1;
+        }
+        if (k != nvals || k > 256) return false;
+        memcpy(h.vals, vals, (size_t)nvals);
+        h.present = true;
+        return true;
+    }
+
+    // jidctint.c (accurate integer IDCT): CONST_BITS 13, PASS1_BITS 2
+    static void idct(const int in[64], uint8_t* out, int stride)
+    {
+        constexpr long F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633,
+                       F1501 = 12299, F1847 = 15137, F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
+        long ws[64];
+        auto descale = [](long x, int nbits) { return (x + (1L << (nbits - 1))) >> nbits; };
+        auto pass = [&](const long* src, int sstep, long* dst, int dstep, int shift) {
+            long z2 = src[2 * sstep], z3 = src[6 * sstep];
+            long z1 = (z2 + z3) * F0541;
+            long tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+            z2 = src[0]; z3 = src[4 * sstep];
+            long tmp0 = (z2 + z3) << 13, tmp1 = (z2 - z3) << 13;
+            const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+            tmp0 = src[7 * sstep]; tmp1 = src[5 * sstep]; tmp2 = src[3 * sstep]; tmp3 = src[1 * sstep];
+            z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+            long z4 = tmp1 + tmp3;
+            const long z5 = (z3 + z4) * F1175;
+            tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
+            z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
+            z3 += z5; z4 += z5;
+            tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+            dst[0 * dstep] = descale(tmp10 + tmp3, shift); dst[7 * dstep] = descale(tmp10 - tmp3, shift);
+            dst[1 * dstep] = descale(tmp11 + tmp2, shift); dst[6 * dstep] = descale(tmp11 - tmp2, shift);
+            dst[2 * dstep] = descale(tmp12 + tmp1, shift); dst[5 * dstep] = descale(tmp12 - tmp1, shift);
+            dst[3 * dstep] = descale(tmp13 + tmp0, shift); dst[4 * dstep] = descale(tmp13 - tmp0, shift);
+        };
+        long col[64];
+        for (int i = 0; i < 64; ++i) col[i] = in[i];
+        for (int c = 0; c < 8; ++c) pass(col + c, 8, ws + c, 8, 13 - 2);            // columns
+        for (int r = 0; r < 8; ++r) {
+            long row[8];
+            pass(ws + 8 * r, 1, row, 1, 13 + 2 + 3);                                // rows
+            for (int c = 0; c < 8; ++c) {
+                long v = row[c] + 128;
+                out[(size_t)r * stride + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        }
+    }
+
+    bool decode_scan()
+    {
+        static const uint8_t zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
+                                           41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
+                                           15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55,
+                                           62, 63};
+        const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+        for (int c = 0; c < ncomp; ++c) {
+            Comp& k = comp[c];
+            k.stride = mcux * k.h * 8;
+            k.rows = mcuy * k.v * 8;
+            k.dw = (W * k.h + hmax - 1) / hmax;
+            k.dh = (H * k.v + vmax - 1) / vmax;
+            k.plane.assign((size_t)k.stride * k.rows, 0);
+            k.pred = 0;
+            if (!dc[k.td].present || !ac[k.ta].present || !qt_present[k.tq]) return false;
+        }
+        int until_restart = restart, next_rst = 0;
+        for (int my = 0; my < mcuy; ++my)
+            for (int mx = 0; mx < mcux; ++mx) {
+                if (restart && until_restart == 0) {
+                    // byte-align, expect RSTn
+                    bitbuf = 0; bitcnt = 0;
+                    while (pos + 1 < n && !(d[pos] == 0xFF && d[pos + 1] >= 0xD0 && d[pos + 1] <= 0xD7)) ++pos;
+                    if (pos + 1 >= n || d[pos + 1] != 0xD0 + next_rst) return false;
+                    pos += 2;
+                    next_rst = (next_rst + 1) & 7;
+                    until_restart = restart;
+                    for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
+                }
+                for (int c = 0; c < ncomp; ++c) {
+                    Comp& k = comp[c];
+                    for (int by = 0; by < k.v; ++by)
+                        for (int bx = 0; bx < k.h; ++bx) {
+                            int coef[64] = {0};
+                            const int s = decode(dc[k.td]);
+                            if (s > 11) return false;
+                            k.pred += extend(bits(s), s);
+                            coef[0] = k.pred * qt[k.tq][0];
+                            for (int i = 1; i < 64;) {
+                                const int rs = decode(ac[k.ta]);
+                                const int r = rs >> 4, sz = rs & 15;
+                                if (sz == 0) {
+                                    if (r != 15) break;         // end of block
+                                    i += 16;
+                                    continue;
+                                }
+                                i += r;
+                                if (i > 63) return false;
+                                coef[zigzag[i]] = extend(bits(sz), sz) * qt[k.tq][i];
+                                ++i;
+                            }
+                            if (bad) return false;
+                            idct(coef, &k.plane[((size_t)(my * k.v + by) * 8) * k.stride + (size_t)(mx * k.h + bx) * 8],
+                                 k.stride);
+                        }
+                }
+                if (restart) --until_restart;
+            }
+        return !bad;
+    }
+
+    bool parse()
+    {
+        if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return false;
+        pos = 2;
+        bool have_sof = false;
+        while (pos + 4 <= n) {
+            if (u8() != 0xFF) return false;
+            int m = u8();
+            while (m == 0xFF) m = u8();
+            if (m == 0xD9) return false;                    // EOI before any scan
+            const int len = u16();
+            if (len < 2 || pos + (size_t)(len - 2) > n) return false;
+            const size_t end = pos + (size_t)(len - 2);
+            if (m == 0xDB) {                                // DQT
+                while (pos < end) {
+                    const int pq = u8(), t = pq & 15;
+                    if (t > 3) return false;
+                    for (int i = 0; i < 64; ++i) qt[t][i] = (uint16_t)((pq >> 4) ? u16() : u8());     // zigzag order
+                    qt_present[t] = true;
+                }
+            } else if (m == 0xC0 || m == 0xC1) {            // SOF0 / SOF1 (Huffman, sequential)
+                if (u8() != 8) return false;                // sample precision
+                H = u16(); W = u16(); ncomp = u8();
+                if (W <= 0 || H <= 0 || W > 32768 || H > 32768 || (ncomp != 1 && ncomp != 3)) return false;
+                for (int c = 0; c < ncomp; ++c) {
+                    comp[c].id = u8();
+                    const int hv = u8();
+                    comp[c].h = hv >> 4; comp[c].v = hv & 15; comp[c].tq = u8();
+                    if (comp[c].tq > 3) return false;
+                }
+                have_sof = true;
+            } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+                return false;                               // progressive, lossless, arithmetic
+            } else if (m == 0xC4) {                         // DHT
+                while (pos < end) {
+                    const int tc = u8(), cls = tc >> 4, t = tc & 15;
+                    if (cls > 1 || t > 3) return false;
+                    uint8_t counts[17] = {0};
+                    int total = 0;
+                    for (int i = 1; i <= 16; ++i) { counts[i] = (uint8_t)u8(); total += counts[i]; }
+                    if (total > 256 || pos + (size_t)total > end) return false;
+                    if (!build(cls ? ac[t] : dc[t], counts, d + pos, total)) return false;
+                    pos += (size_t)total;
+                }
+            } else if (m == 0xDD) {                         // DRI
+                restart = u16();
+            } else if (m == 0xEE && len >= 14 && !memcmp(d + pos, "Adobe", 5)) {
+                adobe_rgb = d[pos + 11] == 0;               // transform 0 with three components: RGB
+            } else if (m == 0xDA) {                         // SOS
+                if (!have_sof) return false;
+                const int ns = u8();
+                if (ns != ncomp) return false;              // one interleaved scan only
+                for (int i = 0; i < ns; ++i) {
+                    const int id = u8(), tt = u8();
+                    if (id != comp[i].id) return false;
+                    comp[i].td = tt >> 4; comp[i].ta = tt & 15;
+                    if (comp[i].td > 3 || comp[i].ta > 3) return false;
+                }
+                pos = end;
+                if (ncomp == 1) { comp[0].h = comp[0].v = 1; }      // a single component is never interleaved
+                hmax = vmax = 1;
+                for (int c = 0; c < ncomp; ++c) {
+                    if (comp[c].h < 1 || comp[c].v < 1) return false;
+                    hmax = comp[c].h > hmax ? comp[c].h : hmax;
+                    vmax = comp[c].v > vmax ? comp[c].v : vmax;
+                }
+                if (ncomp == 3) {
+                    const bool chroma_ok = comp[1].h == 1 && comp[1].v == 1 && comp[2].h == 1 && comp[2].v == 1;
+                    const bool luma_ok = (comp[0].h == 1 || comp[0].h == 2) && (comp[0].v == 1 || comp[0].v == 2) &&
+                                         !(comp[0].h == 1 && comp[0].v == 2);
+                    if (!chroma_ok || !luma_ok) return false;
+                }
+                return decode_scan();
+            }
+            pos = end;
+            if (bad) return false;
+        }
+        return false;
+    }
+
+    // jdsample.c: chroma plane to full resolution, "fancy" (triangle filter) upsampling
+    std::vector<uint8_t> upsample(const Comp& k) const
+    {
+        std::vector<uint8_t> out((size_t)W * H);
+        const int hs = hmax / k.h, vs = vmax / k.v;
+        for (int y = 0; y < H; ++y) {
+            uint8_t* o = &out[(size_t)y * W];
+            if (hs == 1 && vs == 1) {
+                memcpy(o, &k.plane[(size_t)y * k.stride], (size_t)W);
+            } else if (k.dw <= 2) {                         // too narrow for the filter: plain replication
+                const uint8_t* in = &k.plane[(size_t)(y / vs) * k.stride];
+                for (int x = 0; x < W; ++x) o[x] = in[x >> 1];
+            } else if (hs == 2 && vs == 1) {                // h2v1_fancy_upsample
+                const uint8_t* in = &k.plane[(size_t)y * k.stride];
+                for (int x = 0; x < W; ++x) {
+                    const int c = x >> 1;
+                    int v;
+                    if ((x & 1) == 0) v = c == 0 ? in[0] : (in[c] * 3 + in[c - 1] + 1) >> 2;
+                    else v = c == k.dw - 1 ? in[c] : (in[c] * 3 + in[c + 1] + 2) >> 2;
+                    o[x] = (uint8_t)v;
+                }
+            } else {                                        // h2v2_fancy_upsample
+                const int r0 = y >> 1;
+                int r1 = (y & 1) ? r0 + 1 : r0 - 1;         // the further row: below for odd rows, above for even
+                r1 = r1 < 0 ? 0 : (r1 > k.dh - 1 ? k.dh - 1 : r1);
+                const uint8_t* in0 = &k.plane[(size_t)r0 * k.stride];
+                const uint8_t* in1 = &k.plane[(size_t)r1 * k.stride];
+                auto colsum = [&](int c) { return in0[c] * 3 + in1[c]; };
+                for (int x = 0; x < W; ++x) {
+                    const int c = x >> 1, cur = colsum(c);
+                    int v;
+                    if ((x & 1) == 0) v = c == 0 ? (cur * 4 + 8) >> 4 : (cur * 3 + colsum(c - 1) + 8) >> 4;
+                    else v = c == k.dw - 1 ? (cur * 4 + 7) >> 4 : (cur * 3 + colsum(c + 1) + 7) >> 4;
+                    o[x] = (uint8_t)v;
+                }
+            }
+        }
+        return out;
+    }
+};
+
+bool load_jpeg(const std::string& data, Image& im)
+{
+    JpegDecoder j{(const uint8_t*)data.data(), data.size()};
+    if (!j.parse()) return false;
+    im.w = j.W; im.h = j.H;
+    im.rgb.resize((size_t)j.W * j.H * 3);
+    if (j.ncomp == 1) {
+        for (int y = 0; y < j.H; ++y)
+            for (int x = 0; x < j.W; ++x) {
+                const uint8_t g = j.comp[0].plane[(size_t)y * j.comp[0].stride + x];
+                uint8_t* o = &im.rgb[((size_t)y * j.W + x) * 3];
+                o[0] = o[1] = o[2] = g;
+            }
+        return true;
+    }
+    const std::vector<uint8_t> Y = j.upsample(j.comp[0]), Cb = j.upsample(j.comp[1]), Cr = j.upsample(j.comp[2]);
+    // jdcolor.c: 16-bit fixed-point tables, FIX(x) = (int)(x * 65536 + 0.5)
+    auto clamp = [](int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+    for (size_t i = 0; i < (size_t)j.W * j.H; ++i) {
+        uint8_t* o = &im.rgb[i * 3];
+        if (j.adobe_rgb) { o[0] = Y[i]; o[1] = Cb[i]; o[2] = Cr[i]; continue; }
+        const int y = Y[i], cb = Cb[i] - 128, cr = Cr[i] - 128;
+        const int r = y + (int)((91881L * cr + 32768) >> 16);
+        const int g = y + (int)((-22554L * cb - 46802L * cr + 32768) >> 16);
+        const int b = y + (int)((116130L * cb + 32768) >> 16);
+        o[0] = clamp(r); o[1] = clamp(g); o[2] = clamp(b);
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------- parsed object
 struct MaterialRec {
     std::string name;
@@ -420,7 +763,7 @@ struct Builder {
     {
         std::string data;
         Image im;
-        if (!read_file(dir + name, data) || !(load_png(data, im) || load_ppm(data, im) || load_bmp(data, im))) {
+        if (!read_file(dir + name, data) || !(load_png(data, im) || load_jpeg(data, im) || load_ppm(data, im) || load_bmp(data, im))) {
             fprintf(stderr, "rt_obj: cannot decode image map %s%s (kept as a constant colour)\n",
                     dir.c_str(), name.c_str());
             return -1;                                       // IMG_Load failed, :360-363

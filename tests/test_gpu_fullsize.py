@@ -212,6 +212,51 @@ def test_config3_bunny_class_4k_shaded_frame():
                            check_rows=(200, 700, 1000, 1081, 1400, 1900), min_shadow_launches=5)
 
 
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+
+
+def test_config2_whole_1080p_frame_against_the_oracles_golden():
+    """Configuration 2 at full size: EVERY pixel of the 1920x1080 frame of a 20 000-triangle mesh
+    with materials against the hit ids the CPU oracle computed for it (a committed fixture: the
+    oracle needs five minutes on eight cores for this frame, tests/golden/make_fullframe_golden.py),
+    and the 8-bit colours of every 8th row within 1/255."""
+    g = _golden("config2_sphere20k_1080p_f3")
+    mesh = scenes.with_materials(scenes.sphere(20000), num_mats=4, seed=11)
+    assert mesh.num_tris == int(g["triangles"])
+    W, H = 1920, 1080
+    fr = kernel.driver_frame(3)
+    sc = kernel.Scene(mesh)
+    sc.transform(kernel.frame_matrix(fr, "obmat"))
+    out = sc.render_rows(fr, W, H, TAN_HALF, want=("hit", "rgb8"))
+    hit = out["hit"].cpu().numpy()
+    assert (g["hit"] >= 0).sum() > 0.5 * W * H
+    mism = int((hit != g["hit"]).sum())
+    assert mism == 0, f"{mism} of {W * H} hit ids differ from the oracle's"
+    rows = g["rgb8_rows"]
+    d = np.abs(out["rgb8"].cpu().numpy()[rows].astype(int) - g["rgb8"].astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    sc.close()
+
+
+def test_config3_whole_4k_frame_against_the_oracles_golden():
+    """Configuration 3 at full size: every one of the 8 294 400 primary rays of the 69 451-triangle
+    mesh against the oracle's hit ids (committed fixture; half an hour of CPU time)."""
+    g = _golden("config3_torus69451_4k_f7")
+    mesh = scenes.torus(69451)
+    assert mesh.num_tris == int(g["triangles"])
+    W, H = 3840, 2160
+    fr = kernel.driver_frame(7)
+    sc = kernel.Scene(mesh)
+    sc.transform(kernel.frame_matrix(fr, "obmat"))
+    hit, _ = sc.trace_primary(W, H, TAN_HALF)
+    mism = int((hit.cpu().numpy() != g["hit"]).sum())
+    assert (g["hit"] >= 0).sum() > 0.2 * W * H
+    assert mism == 0, f"{mism} of {W * H} hit ids differ from the oracle's"
+    sc.close()
+
+
 def test_config5_rotation_sequence_frames():
     """Config 5: teapot-class mesh, per-frame M3d transform over an orbit; a few frames of the
     360-frame sequence at 4K, sampled rows against the oracle, and no drift: frame k rendered
