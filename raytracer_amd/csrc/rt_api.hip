@@ -853,12 +853,13 @@ static int anyhit_buffers(rt_scene* sc, size_t entries)
 
 // fp64 confirmation of the candidate lists of n rays + the overflow fallback + statistics
 static int resolve_rays(rt_scene* sc, const RayWorkspace& ws, int n, const double* S, const double* E,
-                        bool anyhit, int32_t* hit, double* tuv, double* point, uint8_t* occ)
+                        bool anyhit, int32_t* hit, double* tuv, double* point, uint8_t* occ,
+                        const int32_t* gate = nullptr, long gate_n = 0)
 {
     RtGlobal& g = rt_g();
     const ExactScene es = exact_of(sc);
     RT_TRY(rt_launch_resolve_rays(es, n, S, E, ws.cnt, ws.list, anyhit, hit, tuv, point, occ, ws.ovf,
-                                  ws.counters, g.stream));
+                                  ws.counters, gate, gate_n, g.stream));
     RT_TRY(rt_launch_overflow_rays(es, S, E, ws.ovf, ws.counters, anyhit, hit, tuv, point, occ,
                                    ws.partials, g.stream));
     if (!g.profiling) return RT_OK;        // (the record below is only kept while profiling)
@@ -952,7 +953,8 @@ static int prepare_lights_aside(rt_scene* sc, const rt_frame* f, int lights)
 // Apex sweeps over planes packed relative to each light (rt_sweep_apex.hip), RT_APEX_LIGHTS
 // lights per launch; the rays of a light are binned by the dominant axis of their direction.
 static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, int row_block,
-                             const double* S, const double* E, uint8_t* occ, bool first_group_aside)
+                             const double* S, const double* E, const int32_t* hit, uint8_t* occ,
+                             bool first_group_aside)
 {
     hipStream_t st = rt_g().stream;
     const size_t npix = (size_t)W * nrows;
@@ -992,7 +994,7 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
         auto sweep = [&](const SweepArgs& r) { return rt_launch_sweep_apex(r, st); };
         RT_HIP(hipMemsetAsync(sc->ws_live.p, 0, sizeof(int) * 3 * RT_APEX_SETS, st));
         if (!use_cache) {
-            RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, 1, 0, act0, live0, st));
+            RT_TRY(rt_launch_bin_rays(a.S, a.E, hit, W, nrows, lights, (long)npix, 1, 0, act0, live0, st));
             RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
             continue;
         }
@@ -1009,10 +1011,10 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
             a.occ_id = record ? occ_id : nullptr;
             RT_HIP(hipMemsetAsync(live0, 0, sizeof(int) * 3 * RT_APEX_SETS, st));
             if (level == 0) {
-                RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, step, 0, act0, live0, st));
+                RT_TRY(rt_launch_bin_rays(a.S, a.E, hit, W, nrows, lights, (long)npix, step, 0, act0, live0, st));
             } else {
                 const int coarser = RT_SHADOW_STEPS[level - 1];
-                RT_TRY(rt_launch_bin_rays(a.S, a.E, W, nrows, lights, (long)npix, step, coarser, act2, live2, st));
+                RT_TRY(rt_launch_bin_rays(a.S, a.E, hit, W, nrows, lights, (long)npix, step, coarser, act2, live2, st));
                 RT_TRY(rt_launch_try_cached(exact_of(sc), a.S, a.E, act2, live2, sets, (int)npix, (long)npix,
                                             W, nrows, row_block, coarser, record, a.cnt, occ_id, st));
                 RT_TRY(rt_launch_compact(a.cnt, act2, live2, (int)npix, sets, (long)npix, 3, act0, live0, st));
@@ -1020,7 +1022,8 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
             RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
         }
     }
-    return resolve_rays(sc, scene_workspace(sc), (int)(npix * (size_t)L), S, E, true, nullptr, nullptr, nullptr, occ);
+    return resolve_rays(sc, scene_workspace(sc), (int)(npix * (size_t)L), S, E, true, nullptr, nullptr, nullptr, occ,
+                        hit, (long)npix);
 }
 
 extern "C" int rt_trace_rays(rt_scene* sc, int n, const double* S, const double* E, int32_t* hit,
@@ -1135,7 +1138,7 @@ static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, doubl
         a.occ = sc->ws_occ.as<uint8_t>();
         RT_TRY(rt_launch_shadow_setup(a, st));
         RT_TRY(trace_shadow_rays(sc, f, W, rows.rows, rows.parts > 1 ? rows.block : rows.rows, a.shS, a.shE,
-                                 sc->ws_occ.as<uint8_t>(), aside));
+                                 hit, sc->ws_occ.as<uint8_t>(), aside));
     }
     RT_TRY(rt_launch_shade_final(a, st));
     RT_HIP(hipStreamSynchronize(st));

@@ -175,10 +175,12 @@ __global__ void __launch_bounds__(RT_WG)
 k_resolve_rays(ExactScene es, int n, const double* __restrict__ Sa, const double* __restrict__ Ea,
                const int32_t* __restrict__ cnt, const int32_t* __restrict__ list,
                int32_t* __restrict__ hit, double* __restrict__ tuv, double* __restrict__ point,
-               uint8_t* __restrict__ occ_out, int32_t* __restrict__ ovf, int* __restrict__ counters)
+               uint8_t* __restrict__ occ_out, int32_t* __restrict__ ovf, int* __restrict__ counters,
+               const int32_t* __restrict__ gate, long gate_n)
 {
     int total = 0, live_rays = 0;
     for (long p = (long)blockIdx.x * RT_WG + threadIdx.x; p < n; p += (long)gridDim.x * RT_WG) {
+        if (gate && gate[p % gate_n] < 0) continue;     // no such ray: its slots were never written
         const double Sx = Sa[3 * p];
         if (!(Sx == Sx)) {                      // NaN origin = unused ray slot
             if (ANYHIT) occ_out[p] = 0; else hit[p] = -1;
@@ -508,16 +510,17 @@ int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_hal
 int rt_launch_resolve_rays(const ExactScene& es, int n, const double* S, const double* E,
                            const int32_t* cnt, const int32_t* list, bool anyhit, int32_t* hit,
                            double* tuv, double* point, uint8_t* occ, int32_t* ovf, int* counters,
-                           hipStream_t st)
+                           const int32_t* gate, long gate_n, hipStream_t st)
 {
     if (n <= 0) return RT_OK;
+    if (gate && gate_n <= 0) gate = nullptr;
     dim3 grid((n + RT_WG - 1) / RT_WG < RESOLVE_GRID ? (n + RT_WG - 1) / RT_WG : RESOLVE_GRID);
     if (anyhit)
         hipLaunchKernelGGL(k_resolve_rays<true>, grid, dim3(RT_WG), 0, st, es, n, S, E, cnt, list,
-                           hit, tuv, point, occ, ovf, counters);
+                           hit, tuv, point, occ, ovf, counters, gate, gate_n);
     else
         hipLaunchKernelGGL(k_resolve_rays<false>, grid, dim3(RT_WG), 0, st, es, n, S, E, cnt, list,
-                           hit, tuv, point, occ, ovf, counters);
+                           hit, tuv, point, occ, ovf, counters, gate, gate_n);
     return launched("resolve_rays");
 }
 

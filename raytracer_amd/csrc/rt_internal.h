@@ -312,8 +312,10 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st);     // any-hit ove
 // shadow rays [light][pixel] -> ray-number lists per (light, dominant axis), stride entries apart
 // Only the rays of pixels whose column and local row are multiples of step_in, and not both
 // multiples of step_out (0: no exclusion): the levels of the occluder cache.
-int rt_launch_bin_rays(const double* S, const double* E, int W, int rows, int lights, long stride,
-                       int step_in, int step_out, int32_t* out, int* out_counts, hipStream_t st);
+// hit (or nullptr): the primary hit of every local pixel; pixels that hit nothing have no rays and
+// their slots in S and E are not read
+int rt_launch_bin_rays(const double* S, const double* E, const int32_t* hit, int W, int rows, int lights,
+                       long stride, int step_in, int step_out, int32_t* out, int* out_counts, hipStream_t st);
 // Pixel spacing of the occluder cache's levels, coarsest first; the last must be 1.  (A third,
 // coarser level -- 16, 4, 1 -- was measured: it saves 4 % of the pair tests and loses more than
 // that to its extra chain of small launches.)
@@ -348,10 +350,12 @@ int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_hal
                               const int32_t* cnt, const int32_t* list,
                               int32_t* hit, double* tuv, int32_t* ovf, int* counters,
                               hipStream_t st);
+// gate (or nullptr): ray p is skipped altogether (no output written) when gate[p % gate_n] < 0:
+// the shadow rays [light][pixel] of pixels whose primary ray hit nothing
 int rt_launch_resolve_rays(const ExactScene& es, int n, const double* S, const double* E,
                            const int32_t* cnt, const int32_t* list, bool anyhit,
                            int32_t* hit, double* tuv, double* point, uint8_t* occ,
-                           int32_t* ovf, int* counters, hipStream_t st);
+                           int32_t* ovf, int* counters, const int32_t* gate, long gate_n, hipStream_t st);
 // `partials`: RT_OVERFLOW_PARTIAL_BYTES of device memory for the partial winners of rays whose
 // sweep is cut into mesh slices
 constexpr size_t RT_OVERFLOW_PARTIAL_BYTES = 32 * 2048;

@@ -104,18 +104,18 @@ __global__ void __launch_bounds__(RT_WG) k_shadow_setup(const ShadeArgs a)
     if (p >= npix) return;
     const DevFrame& f = *a.frame;
     const int s = a.hit[p];
-    double point[3] = {0, 0, 0}, normal[3] = {0, 0, 0};
-    if (s != -1) {
-        hit_point(a, p, point);
-        interp_normal(a, s, a.tuv[3 * p + 1], a.tuv[3 * p + 2], normal);
-    }
+    // a pixel that hit nothing has no shadow rays: its slots are not even written, and every
+    // reader of the ray arrays looks at hit[] first (k_bin_rays, k_resolve_rays)
+    if (s == -1) return;
+    double point[3], normal[3];
+    hit_point(a, p, point);
+    interp_normal(a, s, a.tuv[3 * p + 1], a.tuv[3 * p + 2], normal);
     const double qnan = __builtin_nan("");
     for (int l = 0; l < a.num_lights; ++l) {
         double* S = a.shS + 3 * ((long)l * npix + p);
         double* E = a.shE + 3 * ((long)l * npix + p);
         LightGeom g;
-        g.status = 0;
-        if (s != -1) light_geom(f, l, point, normal, g);
+        light_geom(f, l, point, normal, g);
         if (g.status == 2) {
             S[0] = g.shadow_S[0]; S[1] = g.shadow_S[1]; S[2] = g.shadow_S[2];
             E[0] = f.light_pos[l][0]; E[1] = f.light_pos[l][1]; E[2] = f.light_pos[l][2];

@@ -542,8 +542,9 @@ __global__ void __launch_bounds__(RT_WG, R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES)
 // the screen (they tend to retire together).  Unused slots (NaN origin) are left out, and
 // step_in / step_out select the rays of one level of the occluder cache.
 __global__ void __launch_bounds__(RT_WG)
-k_bin_rays(const double* __restrict__ S, const double* __restrict__ E, int W, int rows, long stride,
-           int step_in, int step_out, int32_t* __restrict__ out, int* __restrict__ out_counts)
+k_bin_rays(const double* __restrict__ S, const double* __restrict__ E, const int32_t* __restrict__ hit,
+           int W, int rows, long stride, int step_in, int step_out, int32_t* __restrict__ out,
+           int* __restrict__ out_counts)
 {
     __shared__ int s_wave[RT_WG / 64][3];
     __shared__ int s_base[3];
@@ -567,6 +568,7 @@ k_bin_rays(const double* __restrict__ S, const double* __restrict__ E, int W, in
         if (px % step_in != 0 || lr % step_in != 0) return -1;
         if (step_out > 0 && px % step_out == 0 && lr % step_out == 0) return -1;
         id = lr * W + px;
+        if (hit && hit[id] < 0) return -1;          // the pixel hit nothing: its ray slots were never written
         const double* s = S + 3 * (long)id;
         const double* en = E + 3 * (long)id;
         const double sx = s[0];
@@ -860,8 +862,8 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
     return RT_E_ARG;
 }
 
-int rt_launch_bin_rays(const double* S, const double* E, int W, int rows, int lights, long stride,
-                       int step_in, int step_out, int32_t* out, int* out_counts, hipStream_t st)
+int rt_launch_bin_rays(const double* S, const double* E, const int32_t* hit, int W, int rows, int lights,
+                       long stride, int step_in, int step_out, int32_t* out, int* out_counts, hipStream_t st)
 {
     if (W <= 0 || rows <= 0 || lights <= 0) return RT_OK;
     if (step_in < 1 || step_out < 0) {
@@ -871,8 +873,8 @@ int rt_launch_bin_rays(const double* S, const double* E, int W, int rows, int li
     const long total = (long)((W + 63) / 64) * ((rows + 15) / 16) * 1024;
     long wgs = (total + RT_WG - 1) / RT_WG;
     if (wgs > 2048) wgs = 2048;
-    hipLaunchKernelGGL(k_bin_rays, dim3((unsigned)wgs, lights), dim3(RT_WG), 0, st, S, E, W, rows, stride,
-                       step_in, step_out, out, out_counts);
+    hipLaunchKernelGGL(k_bin_rays, dim3((unsigned)wgs, lights), dim3(RT_WG), 0, st, S, E, hit, W, rows,
+                       stride, step_in, step_out, out, out_counts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("bin_rays launch failed: %s", hipGetErrorString(e));
