@@ -630,12 +630,19 @@ static int row_map(const rt_rows* r, int H, RowMap* out)
     return RT_OK;
 }
 
+static int lights_fork(rt_scene* sc, int lights);
+static int lights_launch(rt_scene* sc, const rt_frame* f, int lights);
+
+// aside_frame (or nullptr): the frame whose first aside_lights lights are sorted and packed on the
+// scene's side stream beside the sweep (see lights_fork / lights_launch)
 static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const RowMap& rows,
-                              int32_t* hit, double* tuv)
+                              int32_t* hit, double* tuv, const rt_frame* aside_frame = nullptr,
+                              int aside_lights = 0)
 {
     RtGlobal& g = rt_g();
     hipStream_t st = g.stream;
     const size_t npix = (size_t)W * rows.rows;
+    if (aside_frame) RT_TRY(lights_fork(sc, aside_lights));
     int rpl = 1, chunks = 1, waves_x = 4;
     rt_raster_shape(W, rows.rows, sc->num_tris_padded / RT_TILE, &rpl, &chunks, &waves_x);
     // per pixel: a count, a bound and RT_RASTER_LIST_K list slots, shared by all triangle chunks
@@ -672,6 +679,9 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     g.last_raster_rpl.store(rpl, std::memory_order_relaxed);
     g.last_raster_chunks.store(chunks, std::memory_order_relaxed);
     RT_TRY(timed_sweep([&] { return rt_launch_sweep_raster(a, st); }, false, tests, nullptr));
+    // (queued by the host after the sweep, so that the sweep is not kept waiting for a dozen small
+    // launches; on the device the side stream only waits for what preceded the sweep)
+    if (aside_frame) RT_TRY(lights_launch(sc, aside_frame, aside_lights));
     if (g.profiling) g.prof.rays_primary += npix;
 #ifdef RT_RASTER_CHECK_INTERVAL
     {
@@ -929,20 +939,26 @@ static int reserve_light_buffers(rt_scene* sc, int lights)
     return RT_OK;
 }
 
-// Starts prepare_lights for the first group of lights on the scene's side stream, behind
-// everything already queued on the launch stream: the sorts and packs (bandwidth-bound, well
-// under a millisecond) then run beside the primary sweep (instruction-bound) instead of after
-// it.  The any-hit phase waits for ev_join.
-static int prepare_lights_aside(rt_scene* sc, const rt_frame* f, int lights)
+// prepare_lights for the first group of lights on the scene's side stream, beside the primary
+// sweep: the sorts and packs (bandwidth-bound, well under a millisecond) then run while the
+// instruction-bound sweep does, instead of after it.  lights_fork marks, on the launch stream,
+// the point the side stream has to wait for (everything queued before the sweep: the transform,
+// an earlier frame's use of the buffers); lights_launch queues the work; the any-hit phase waits
+// for ev_join.
+static int lights_fork(rt_scene* sc, int lights)
 {
-    hipStream_t st = rt_g().stream;
     if (!sc->side_stream) {
         RT_HIP(hipStreamCreateWithFlags(&sc->side_stream, hipStreamNonBlocking));
         RT_HIP(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
         RT_HIP(hipEventCreateWithFlags(&sc->ev_join, hipEventDisableTiming));
     }
     RT_TRY(reserve_light_buffers(sc, lights));
-    RT_HIP(hipEventRecord(sc->ev_fork, st));
+    RT_HIP(hipEventRecord(sc->ev_fork, rt_g().stream));
+    return RT_OK;
+}
+
+static int lights_launch(rt_scene* sc, const rt_frame* f, int lights)
+{
     RT_HIP(hipStreamWaitEvent(sc->side_stream, sc->ev_fork, 0));
     const int rc = prepare_lights(sc, f, 0, lights, sc->side_stream);
     RT_HIP(hipEventRecord(sc->ev_join, sc->side_stream));      // also after a failed launch: the join must not hang
@@ -1094,8 +1110,8 @@ static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, doubl
     // the first group of lights is sorted and packed on a side stream beside the primary sweep
     static const bool aside_env = !(getenv("RT_AMD_LIGHTS_ASIDE") && atoi(getenv("RT_AMD_LIGHTS_ASIDE")) == 0);
     const bool aside = L > 0 && aside_env;
-    if (aside) RT_TRY(prepare_lights_aside(sc, f, L < RT_APEX_LIGHTS ? L : RT_APEX_LIGHTS));
-    RT_TRY(trace_primary_rows(sc, W, H, tan_half, rows, hit, tuv));
+    RT_TRY(trace_primary_rows(sc, W, H, tan_half, rows, hit, tuv, aside ? f : nullptr,
+                              L < RT_APEX_LIGHTS ? L : RT_APEX_LIGHTS));
 
     // frame constants
     DevBuf& frame_dev = sc->ws_frame;
