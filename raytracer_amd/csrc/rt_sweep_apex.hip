@@ -680,14 +680,15 @@ int rt_device_cus()
 // small bands.  The chunks of a pixel share its candidate list and closest-hit bound (atomics in
 // the rare path), so their number costs neither memory nor pruning: about 24 rounds of
 // workgroups, 61 chunks for a 3840x2160 frame of a million triangles, some 480 for an eighth of
-// it.  A chunk keeps at least 8 tiles; a mesh too small to fill the machine that way gives up
-// pixels per lane instead.  RT_AMD_RASTER_FORCE="<pixels per lane>,<chunks>[,<waves side by
+// it.  A chunk may be as short as one tile (measured: a 6 k-triangle mesh at 3840x2160 sweeps in
+// 2.7 ms with 49 one-tile chunks, 3.3 ms with 6 chunks of 8); a mesh too small to fill the machine
+// even so gives up pixels per lane instead.  RT_AMD_RASTER_FORCE="<pixels per lane>,<chunks>[,<waves side by
 // side, 0 = dealt row by row>]" overrides the choice (read at every call: tests use it to run
 // every kernel shape on small inputs).
 void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks, int* waves_x)
 {
     const long slots = 5L * rt_device_cus();           // resident workgroups
-    int max_chunks = tiles / 8;
+    int max_chunks = tiles;                            // a chunk may be a single tile
     if (max_chunks < 1) max_chunks = 1;
     // (the chunks of a pixel share its candidate list, so their number costs no memory)
     static const int env_cap = getenv("RT_AMD_RASTER_MAX_CHUNKS") ? atoi(getenv("RT_AMD_RASTER_MAX_CHUNKS")) : 0;
@@ -786,13 +787,15 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
     return RT_E_ARG;
 }
 
-// Triangle chunks an any-hit launch over `tiles` tiles may use: each at least 8 tiles long.
-// (The chunks of a ray share its count and list, so unlike the closest-hit sweep's they cost no
-// memory.)
-static int apex_max_chunks(int tiles)
+// Triangle chunks an any-hit launch over `tiles` tiles of a mesh of `mesh_tiles` may use: each at
+// least 8 tiles long, 2 where the whole mesh is too small to fill the machine otherwise (measured:
+// the shadow rays of a 6 k-triangle mesh at 640x480 take 0.19 ms instead of 0.33 ms; on meshes of
+// 70 k triangles and more the shorter chunks cost 3 to 5 %).  (The chunks of a ray share its
+// count and list, so their number costs no memory.)
+static int apex_max_chunks(int tiles, int mesh_tiles)
 {
     static const int cap = getenv("RT_AMD_APEX_MAX_CHUNKS") ? atoi(getenv("RT_AMD_APEX_MAX_CHUNKS")) : 256;
-    int c = tiles / 8;
+    int c = tiles / (mesh_tiles < 128 ? 2 : 8);
     if (c > cap) c = cap;
     return c < 1 ? 1 : c;
 }
@@ -832,7 +835,7 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
     }
     if (a.n_rays <= 0) return RT_OK;
     const int tiles = (a.tri_end - a.tri_begin) / RT_TILE;
-    const int max_chunks = apex_max_chunks(tiles);
+    const int max_chunks = apex_max_chunks(tiles, a.num_tris_padded / RT_TILE);
     // shape from the host's estimate of the live rays where it has one (the bound may be a range stale)
     const long shape_rays = a.est_rays > 0 ? a.est_rays : (a.total_rays > 0 ? a.total_rays : (long)a.n_rays * a.lights);
     int r = apex_rays_per_lane(shape_rays, max_chunks);
