@@ -208,7 +208,9 @@ int rt_place_rows_part(const uint8_t* rgb8, int W, int H, const rt_rows* rows, u
  * device inside the call; the interface stays blocking and single-caller), moves the finished
  * 8-bit rows to the first device over RCCL (one group of ncclSend / ncclRecv, xGMI point to
  * point) and places them there (driver.c:186-190).  RCCL is loaded at run time, and only for more
- * than one device.  Not usable while a user stream is set (rt_set_stream).
+ * than one device; where it cannot be loaded or initialised the rows travel by peer copies
+ * instead (rt_multi_exchange tells which, and why).  Not usable while a user stream is set
+ * (rt_set_stream).
  *   devices        n_devices HIP ordinals, or NULL for 0 .. n_devices-1
  *   for_each_scene calls fn(scene of part i, i, user) with that scene's device current, one after
  *                  the other, for the rt_scene_set_* uploads; rt_multi_set_obj does it for a loaded
@@ -219,6 +221,7 @@ typedef struct rt_multi rt_multi;
 int rt_multi_create(rt_multi** out, int n_devices, const int* devices);
 int rt_multi_destroy(rt_multi* m);
 int rt_multi_num_devices(const rt_multi* m);
+const char* rt_multi_exchange(const rt_multi* m);   /* "rccl", "copy" or "copy (<why RCCL is not used>)" */
 int rt_multi_for_each_scene(rt_multi* m, int (*fn)(rt_scene* scene, int part, void* user), void* user);
 int rt_multi_set_obj(rt_multi* m, const rt_obj* o);
 int rt_multi_transform(rt_multi* m, const double obmat[4][4]);

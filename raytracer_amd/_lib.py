@@ -118,6 +118,7 @@ SIGNATURES = {
     "rt_multi_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, c_int_p]),
     "rt_multi_destroy": (C.c_int, [C.c_void_p]),
     "rt_multi_num_devices": (C.c_int, [C.c_void_p]),
+    "rt_multi_exchange": (C.c_char_p, [C.c_void_p]),
     "rt_multi_for_each_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_multi_set_obj": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_multi_transform": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -80,6 +80,8 @@ struct rt_multi {
     Rccl rccl;
     std::vector<ncclComm_t> comms;  // one per device when the exchange goes over RCCL
     bool use_rccl = false;
+    std::string rccl_failure;       // why a set of distinct devices exchanges by peer copies after all
+    std::string exchange;           // rt_multi_exchange's answer
     DevBuf gathered;                // on device 0: the rows of devices 1.. back to back
 };
 
@@ -187,6 +189,13 @@ extern "C" int rt_multi_create(rt_multi** out, int n_devices, const int* devices
             rc = check_nccl(m, m->rccl.CommInitAll(m->comms.data(), n_devices, list.data()), "ncclCommInitAll");
             if (rc) m->comms.clear();
         }
+        // a machine without a usable RCCL still renders: the rows then travel by peer copies
+        // (the reason stays readable through rt_multi_exchange); RT_AMD_MULTI_EXCHANGE=rccl insists
+        if (rc != RT_OK && !force_rccl) {
+            m->rccl_failure = rt_last_error();
+            m->use_rccl = false;
+            rc = RT_OK;
+        }
     }
     if (rc) {
         std::string keep = rt_last_error();
@@ -194,9 +203,12 @@ extern "C" int rt_multi_create(rt_multi** out, int n_devices, const int* devices
         rt_set_error("%s", keep.c_str());
         return rc;
     }
+    m->exchange = m->use_rccl ? "rccl" : (m->rccl_failure.empty() ? "copy" : "copy (" + m->rccl_failure + ")");
     *out = m;
     return RT_OK;
 }
+
+extern "C" const char* rt_multi_exchange(const rt_multi* m) { return m ? m->exchange.c_str() : ""; }
 
 extern "C" int rt_multi_destroy(rt_multi* m)
 {

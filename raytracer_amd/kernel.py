@@ -339,6 +339,11 @@ class MultiScene:
             raise errors[0]
         check(rc, "rt_multi_for_each_scene")
 
+    @property
+    def exchange(self) -> str:
+        """How the rows reach the first device: "rccl", "copy" or "copy (<why not RCCL>)"."""
+        return self.lib.rt_multi_exchange(self.h).decode()
+
     def transform(self, m) -> None:
         m = _mat(m)
         check(self.lib.rt_multi_transform(self.h, m.ctypes.data), "rt_multi_transform")

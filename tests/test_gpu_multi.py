@@ -34,6 +34,7 @@ def test_multi_frame_equals_single_scene_frame(devices, exchange, monkeypatch):
     mesh = scenes.with_materials(scenes.torus(3000))
     W, H = 200, 150                   # 150 rows: the last round of 16-row blocks is a partial one
     ms = kernel.MultiScene(mesh, devices)
+    assert ms.exchange == ("rccl" if exchange == "rccl" else "copy")
     for frame_no in (0, 7):
         fr = kernel.driver_frame(frame_no)
         ms.transform(kernel.frame_matrix(fr, "obmat"))

@@ -43,6 +43,7 @@ def test_no_device_fails_loudly():
     assert lib.rt_scene_create(C.byref(h)) == -5     # nothing falls back to the CPU
     assert lib.rt_multi_create(C.byref(h), 2, None) == -5 and not h.value
     assert lib.rt_multi_num_devices(None) == 0 and lib.rt_multi_destroy(None) == 0
+    assert lib.rt_multi_exchange(None) == b""
 
 
 def test_reference_struct_layout():
