@@ -275,6 +275,17 @@ int rt_apex_sweep_config(int* tile_tris, int* primary_pixels_per_lane,
  * not by flops: most of its arithmetic is additions that step a plane distance from one pixel
  * of the lane to the next. */
 int rt_raster_sweep_mix(int* pixels_per_lane, int* fma, int* add, int* logic, int* compare);
+/* Tile culling (off by default): before a tile of 128 triangles meets a wave's rays one by one,
+ * every triangle of the tile is tested once against the wave's whole bundle -- the pixel
+ * rectangle of a primary-ray wave, the direction box of a shadow-ray wave -- with the same
+ * conservative edge functions, and only the survivors go through the per-ray tests.  Every
+ * wave still visits every triangle and the results are bit for bit the same (the candidates
+ * handed to the fp64 pass remain a superset of the true hits); what changes is that most
+ * (ray, triangle) pairs are decided a few thousand at a time.  The default keeps the all-pairs
+ * sweep of triangle_intersection.cu:167-176, which is what the throughput figures in tests per
+ * second refer to.  on: 1 / 0, or -1 to follow the environment variable RT_AMD_CULL again. */
+int rt_set_tile_culling(int on);
+int rt_get_tile_culling(void);
 int rt_profile_enable(int on);     /* wraps sweep launches in HIP events and reads the device
                                       counters back (adds a sync per launch); the ray and
                                       candidate counts above are only collected while on */

@@ -147,6 +147,16 @@ extern "C" int rt_raster_sweep_mix(int* pixels_per_lane, int* fma, int* add, int
 }
 
 extern "C" int rt_profile_enable(int on) { rt_g().profiling = on != 0; return RT_OK; }
+
+bool rt_tile_culling()
+{
+    const int set = rt_g().tile_culling;
+    if (set >= 0) return set != 0;
+    const char* e = getenv("RT_AMD_CULL");      // read at every call: tests switch it
+    return e && atoi(e) != 0;
+}
+extern "C" int rt_set_tile_culling(int on) { rt_g().tile_culling = on < 0 ? -1 : (on != 0); return RT_OK; }
+extern "C" int rt_get_tile_culling(void) { return rt_tile_culling() ? 1 : 0; }
 extern "C" int rt_profile_reset(void) { rt_g().prof = rt_profile{}; return RT_OK; }
 extern "C" int rt_profile_get(rt_profile* out)
 {
@@ -670,6 +680,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     a.best_hi = sc->ws_besthi.as<float>();
     a.chunks = chunks;
     a.waves_x = waves_x;
+    a.cull = rt_tile_culling() ? 1 : 0;
     a.tests = nullptr;
 #ifdef RT_RASTER_CHECK_INTERVAL
     a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
@@ -833,7 +844,7 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
         RT_HIP(hipMemsetAsync(live_dev[cur ^ 1], 0, sizeof(int) * RT_APEX_SETS, st));
         RT_TRY(rt_launch_compact(a.cnt, indexed ? act[cur] : nullptr, indexed ? live_dev[cur] : nullptr,
                                  indexed ? live : n, sets, stride, cnt_div, act[cur ^ 1], live_dev[cur ^ 1],
-                                 st));
+                                 sc->ws_live.as<int>() + 3 * RT_APEX_SETS, st));
         posted = slot_next % kCountSlots;
         ++slot_next;
         RT_TRY(post_counts(live_dev[cur ^ 1], posted));
@@ -857,7 +868,7 @@ static int anyhit_buffers(rt_scene* sc, size_t entries)
 {
     RT_TRY(sc->ws_act0.reserve(sizeof(int32_t) * entries));
     RT_TRY(sc->ws_act1.reserve(sizeof(int32_t) * entries));
-    RT_TRY(sc->ws_live.reserve(sizeof(int) * 3 * RT_APEX_SETS));
+    RT_TRY(sc->ws_live.reserve(sizeof(int) * (3 + RT_COMPACT_SLICES) * RT_APEX_SETS));   // counts + the compaction's slice sums
     return RT_OK;
 }
 
@@ -996,6 +1007,7 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
         static const bool sort_tris = !(getenv("RT_AMD_SORT_TRIS") && atoi(getenv("RT_AMD_SORT_TRIS")) == 0);
         int32_t* order = sort_tris ? sc->tri_order.as<int32_t>() : nullptr;
         SweepArgs a{};
+        a.cull = rt_tile_culling() ? 1 : 0;
         a.tri_order = order;
         a.planes = sc->planes_light.as<float4>(); a.plane_stride = sc->num_tris_padded;
         a.light_plane_stride = (long)RT_APEX_PLANES * sc->num_tris_padded;
@@ -1033,7 +1045,8 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
                 RT_TRY(rt_launch_bin_rays(a.S, a.E, hit, W, nrows, lights, (long)npix, step, coarser, act2, live2, st));
                 RT_TRY(rt_launch_try_cached(exact_of(sc), a.S, a.E, act2, live2, sets, (int)npix, (long)npix,
                                             W, nrows, row_block, coarser, record, a.cnt, occ_id, st));
-                RT_TRY(rt_launch_compact(a.cnt, act2, live2, (int)npix, sets, (long)npix, 3, act0, live0, st));
+                RT_TRY(rt_launch_compact(a.cnt, act2, live2, (int)npix, sets, (long)npix, 3, act0, live0,
+                                         sc->ws_live.as<int>() + 3 * RT_APEX_SETS, st));
             }
             RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
         }

@@ -177,12 +177,14 @@ struct RtGlobal {
     int device = -1;
     hipStream_t stream = nullptr;
     bool profiling = false;
+    int tile_culling = -1;                  // rt_set_tile_culling; -1: not set, RT_AMD_CULL decides
     std::atomic<int> last_raster_rpl{0};    // pixels per lane of the most recent primary sweep
     std::atomic<int> last_raster_chunks{0}; // and its triangle chunks
     rt_profile prof{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 RtGlobal& rt_g();
+bool rt_tile_culling();     // the setting in force (rt_set_tile_culling, else RT_AMD_CULL, else off)
 int rt_ensure_init();
 int rt_device_cus();        // compute units of the device (cached; every device of a node is alike)
 
@@ -279,6 +281,7 @@ struct SweepArgs {
     // (+inf before the sweep); cnt[] must be zero before the sweep
     float* best_hi;
     unsigned long long* tests;   // pairs evaluated, accumulated per workgroup (may be nullptr)
+    int cull;               // apex sweeps: test every tile's triangles against the wave's whole bundle first
 };
 int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st);
 // rt_sweep_apex.hip: a.planes = apex planes (RT_APEX_PLANES of them)
@@ -333,8 +336,11 @@ int rt_launch_sort_triangles(rt_scene* sc, const double apex[3], int32_t* order,
 int rt_launch_sort_rays(rt_scene* sc, const double* S, const double* E, const int32_t* ids_in,
                         int32_t* ids_out, const int* counts, const int* counts_dev, int sets,
                         long stride, hipStream_t st);
+// slice_counts: RT_COMPACT_SLICES ints per set, scratch
+constexpr int RT_COMPACT_SLICES = 2048;
 int rt_launch_compact(const int32_t* cnt, const int32_t* in, const int* in_counts, int n, int sets,
-                      long stride, int cnt_div, int32_t* out, int* out_counts, hipStream_t st);
+                      long stride, int cnt_div, int32_t* out, int* out_counts, int* slice_counts,
+                      hipStream_t st);
 
 // rt_exact.hip
 struct ExactScene {

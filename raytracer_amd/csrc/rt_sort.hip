@@ -4,7 +4,7 @@
 // wave's 64 R rays lies in the triangle's u slab.  Rays of neighbouring pixels are neighbours
 // on a smooth surface, but where neighbouring pixels see different depths (a triangle soup,
 // silhouettes) their shadow rays fan out along the light's epipolar lines.  Ordering the rays
-// of a set by a Morton code of the two minor components of D' = D / D_k makes every wave's
+// of a set along a Hilbert curve over the two minor components of D' = D / D_k makes every wave's
 // rays a narrow bundle through the light, which fewer slabs cross, and whose rays tend to
 // share occluders and retire together.  An any-hit query does not depend on the order in
 // which rays are swept, so the results are unchanged.
@@ -18,14 +18,28 @@ struct KeyArgs {
     int key_off[RT_APEX_SETS];      // where the keys of set s start in the packed key array
 };
 
-__device__ __forceinline__ unsigned spread_bits(unsigned x)     // bit i of 12 -> bit 2 i
+// Position of the cell (x, y) of a 4096 x 4096 grid along the Hilbert curve.  Unlike the Z
+// order, consecutive positions are always neighbouring cells, so any run of consecutive rays
+// covers a compact patch of directions (a Z-order run that straddles a quadrant boundary spans
+// half the grid).
+__device__ __forceinline__ unsigned hilbert_index(unsigned x, unsigned y)
 {
-    x &= 0xFFFu;
-    x = (x | (x << 8)) & 0x00FF00FFu;
-    x = (x | (x << 4)) & 0x0F0F0F0Fu;
-    x = (x | (x << 2)) & 0x33333333u;
-    x = (x | (x << 1)) & 0x55555555u;
-    return x;
+    unsigned d = 0;
+#pragma unroll
+    for (unsigned s = 2048u; s > 0u; s >>= 1) {
+        const unsigned rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (ry == 0u) {
+            if (rx == 1u) {
+                x = 4095u - x;
+                y = 4095u - y;
+            }
+            const unsigned t = x;
+            x = y;
+            y = t;
+        }
+    }
+    return d;
 }
 
 // blockIdx.y = set = light * 3 + dominant axis; ids of set s at ids[s * stride ...], n = counts[s]
@@ -49,7 +63,7 @@ k_ray_keys(const double* __restrict__ S, const double* __restrict__ E, const int
         const float u = (float)(du / dk), v = (float)(dv / dk);
         const unsigned qu = (unsigned)fminf(fmaxf((u + 1.0f) * 2047.5f, 0.0f), 4095.0f);
         const unsigned qv = (unsigned)fminf(fmaxf((v + 1.0f) * 2047.5f, 0.0f), 4095.0f);
-        keys[i] = spread_bits(qu) | (spread_bits(qv) << 1) | (dk < 0.0 ? 1u << 24 : 0u);
+        keys[i] = hilbert_index(qu, qv) | (dk < 0.0 ? 1u << 24 : 0u);
     }
 }
 

@@ -222,19 +222,24 @@ __global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep(const SweepArgs A
 
 // Survivors of an any-hit range: rays that are neither certainly occluded nor unused.
 // `in` == nullptr means "all rays 0..n-1".  blockIdx.y = ray set (see SweepArgs).  Each
-// workgroup owns one contiguous slice of the input, counts its survivors, reserves their place
-// in the output with a single atomic and writes them in input order, so rays that were
-// neighbours stay neighbours.
+// workgroup owns one contiguous slice of the input.  WRITE == false: it counts its survivors
+// into slice_counts[set][workgroup].  WRITE == true (a second launch of the same shape): its
+// place in the output is the sum of the counts of the slices before it, and it writes its
+// survivors there in input order.  The output keeps the order of the input throughout: rays
+// sorted by direction stay sorted, and a wave's rays stay one narrow bundle.
+constexpr int kCompactSlices = RT_COMPACT_SLICES;
+template <bool WRITE>
 __global__ void __launch_bounds__(RT_WG)
 k_compact(const int32_t* __restrict__ cnt, const int32_t* __restrict__ in,
           const int* __restrict__ in_counts, int n, long stride, int cnt_div,
-          int32_t* __restrict__ out, int* __restrict__ out_counts)
+          int32_t* __restrict__ out, int* __restrict__ out_counts, int* __restrict__ slice_counts)
 {
     __shared__ int s_wave[RT_WG / 64];
-    __shared__ int s_base;
+    __shared__ int s_before[RT_WG / 64], s_total[RT_WG / 64];
     const long set = blockIdx.y;
     cnt += (set / cnt_div) * stride;
     out += set * stride;
+    slice_counts += set * kCompactSlices;
     if (in) {
         in += set * stride;
         if (in_counts) n = in_counts[set];
@@ -243,40 +248,66 @@ k_compact(const int32_t* __restrict__ cnt, const int32_t* __restrict__ in,
     // slice of this workgroup, a multiple of the workgroup size
     const long per = ((long)(n + gridDim.x - 1) / gridDim.x + RT_WG - 1) / RT_WG * RT_WG;
     const long lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
-    if (lo >= n) return;
     auto survivor = [&](long j) {
         if (j >= hi) return -1;
         const int id = in ? in[j] : (int)j;
         return (cnt[id] & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) ? -1 : id;
     };
-    int mine = 0;
-    for (long j = lo + threadIdx.x; j - threadIdx.x < hi; j += RT_WG) mine += survivor(j) >= 0;
+    if (!WRITE) {
+        int mine = 0;
+        for (long j = lo + threadIdx.x; j - threadIdx.x < hi; j += RT_WG) mine += survivor(j) >= 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-    if (lane == 0) s_wave[wave] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int total = 0;
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+        if (lane == 0) s_wave[wave] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int total = 0;
 #pragma unroll
-        for (int k = 0; k < RT_WG / 64; ++k) total += s_wave[k];
-        s_base = total ? atomicAdd(&out_counts[set], total) : 0;
+            for (int k = 0; k < RT_WG / 64; ++k) total += s_wave[k];
+            slice_counts[blockIdx.x] = total;       // 0 for a slice beyond the end
+        }
+        return;
+    }
+    // survivors in the slices before this one, and (first workgroup) in all of them
+    int before = 0, total = 0;
+    for (int k = threadIdx.x; k < (int)gridDim.x; k += RT_WG) {
+        const int c = slice_counts[k];
+        before += k < (int)blockIdx.x ? c : 0;
+        total += c;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        before += __shfl_xor(before, off);
+        total += __shfl_xor(total, off);
+    }
+    if (lane == 0) {
+        s_before[wave] = before;
+        s_total[wave] = total;
     }
     __syncthreads();
-    int base = s_base;
+    int base = 0;
+    total = 0;
+#pragma unroll
+    for (int k = 0; k < RT_WG / 64; ++k) {
+        base += s_before[k];
+        total += s_total[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_counts[set] = total;
+    if (lo >= n) return;
     for (long j = lo + threadIdx.x; j - threadIdx.x < hi; j += RT_WG) {
         const int id = survivor(j);
         const unsigned long long m = __ballot(id >= 0);
         __syncthreads();                 // s_wave is reused every round
         if (lane == 0) s_wave[wave] = __popcll(m);
         __syncthreads();
-        int before = 0, total = 0;
+        int ahead = 0, round = 0;
 #pragma unroll
         for (int k = 0; k < RT_WG / 64; ++k) {
-            before += k < wave ? s_wave[k] : 0;
-            total += s_wave[k];
+            ahead += k < wave ? s_wave[k] : 0;
+            round += s_wave[k];
         }
-        if (id >= 0) out[base + before + __popcll(m & ((1ull << lane) - 1))] = id;
-        base += total;
+        if (id >= 0) out[base + ahead + __popcll(m & ((1ull << lane) - 1))] = id;
+        base += round;
     }
 }
 
@@ -329,13 +360,20 @@ int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st)
 }
 
 int rt_launch_compact(const int32_t* cnt, const int32_t* in, const int* in_counts, int n, int sets,
-                      long stride, int cnt_div, int32_t* out, int* out_counts, hipStream_t st)
+                      long stride, int cnt_div, int32_t* out, int* out_counts, int* slice_counts,
+                      hipStream_t st)
 {
     if (n <= 0 || sets <= 0 || cnt_div <= 0) return RT_OK;
+    if (!slice_counts || sets > RT_APEX_SETS) {
+        rt_set_error("compact: no slice buffer");
+        return RT_E_ARG;
+    }
     long wgs = (n + RT_WG - 1) / RT_WG;
-    if (wgs > 2048) wgs = 2048;         // grid-stride: a workgroup per 256 rays costs more to dispatch than to run
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)wgs, sets), dim3(RT_WG), 0, st, cnt, in, in_counts, n,
-                       stride, cnt_div, out, out_counts);
+    if (wgs > kCompactSlices) wgs = kCompactSlices;     // grid-stride: a workgroup per 256 rays costs more to dispatch than to run
+    hipLaunchKernelGGL(k_compact<false>, dim3((unsigned)wgs, sets), dim3(RT_WG), 0, st, cnt, in, in_counts, n,
+                       stride, cnt_div, out, out_counts, slice_counts);
+    hipLaunchKernelGGL(k_compact<true>, dim3((unsigned)wgs, sets), dim3(RT_WG), 0, st, cnt, in, in_counts, n,
+                       stride, cnt_div, out, out_counts, slice_counts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("compact launch failed: %s", hipGetErrorString(e));

@@ -67,6 +67,16 @@ constexpr int kRasterUnroll = RT_RASTER_UNROLL;
 constexpr int kApexUnroll = RT_APEX_UNROLL;
 
 struct Tri2 { float4 P, Q; };
+
+// (a & b) | c on the bit patterns, as the one instruction it is.  Spelled out because the
+// optimiser otherwise rebalances the chain of these over a lane's pixels into separate ands and
+// a tree of three-input ors: 40 % more instructions and twice the registers.
+__device__ __forceinline__ int and_or(float a, float b, int c)
+{
+    int r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ Tri2 load_tri2(const float4* p) { return {p[0], p[RT_TILE]}; }
 
 // ------------------------------------------------------------------------------------------
@@ -127,7 +137,50 @@ __device__ __forceinline__ void finish_raster(const SweepArgs& A, long slot, int
         atomicMin(reinterpret_cast<int*>(A.best_hi + slot), __float_as_int(t + terr));
 }
 
-template <int R>
+// The pixel rectangle of a wave, for the tile-culling variant: centre and half extents in the
+// units the planes are evaluated in (xs = X / RT_RASTER_COLS for planes 0 and 1, x = X for
+// planes 2 and 3).  All values are multiples of 1/16 below 2^13: exact in fp32.
+struct WaveRect { float xs_c, xs_h, x_c, x_h, y_c, y_h; };
+
+// Can any pixel of the rectangle pass the inside test of this triangle?  The four edge
+// functions are affine in (X, Y), so over the rectangle each is bounded by its centre value
+// and |dX| hx + |dY| hy.  A hit has un < 0, wn < 0 (plane 0, 1: -(U + delta), -(W' + delta)),
+// V >= 0 and det - U - V >= 0 for the orientation-normalised triangle; the rectangle is
+// dropped only when one of them fails everywhere by a clear multiple of the per-pixel test's
+// own allowances (delta for the slab, the margin m = 32 delta for the other two edges), which
+// is far more than the rounding of these few fp32 operations (a few 2^-24 of the same
+// magnitudes delta is 2^-20 of).  A NaN or infinite plane entry makes the comparisons false:
+// the triangle is kept and the per-pixel tests decide as they would without culling.
+__device__ __forceinline__ bool rect_may_hit(const float4& P, const float4& Q, const float4& Hh, const float4& N,
+                                             const WaveRect& w)
+{
+    const float grow = 1.000001f;
+    const float delta = P.w, margin = Q.w;
+    const float cu = __builtin_fmaf(w.xs_c, P.x, __builtin_fmaf(w.y_c, P.y, P.z));
+    const float ru = __builtin_fmaf(__builtin_fabsf(P.x), w.xs_h, __builtin_fabsf(P.y) * w.y_h) * grow;
+    if (cu - ru > delta) return false;
+    const float cw = __builtin_fmaf(w.xs_c, Q.x, __builtin_fmaf(w.y_c, Q.y, Q.z));
+    const float rw = __builtin_fmaf(__builtin_fabsf(Q.x), w.xs_h, __builtin_fabsf(Q.y) * w.y_h) * grow;
+    if (cw - rw > delta) return false;
+    const float cv = __builtin_fmaf(w.x_c, Hh.x, __builtin_fmaf(w.y_c, Hh.y, Hh.z));
+    const float rv = __builtin_fmaf(__builtin_fabsf(Hh.x), w.x_h, __builtin_fabsf(Hh.y) * w.y_h) * grow;
+    if (cv + rv < -2.0f * margin) return false;
+    // W3 = det - U - V with U = -un - delta: coefficients formed here
+    const float inv_cols = 1.0f / RT_RASTER_COLS;
+    const float gx = __builtin_fmaf(P.x, inv_cols, N.x) - Hh.x, gy = (N.y + P.y) - Hh.y;
+    const float gz = ((N.z + P.z) + delta) - Hh.z;
+    const float cg = __builtin_fmaf(w.x_c, gx, __builtin_fmaf(w.y_c, gy, gz));
+    const float rg = __builtin_fmaf(__builtin_fabsf(gx), w.x_h, __builtin_fabsf(gy) * w.y_h) * grow;
+    if (cg + rg < -2.0f * margin) return false;
+    return true;
+}
+
+// CULL: every tile's triangles are first tested against the wave's whole pixel rectangle, one
+// triangle per lane (rect_may_hit), and only the survivors go through the per-pixel tests.
+// The candidates that reach the exact pass are still a superset of the true hits, so the
+// results are the same; what changes is that most (pixel, triangle) pairs are decided 4096 at a
+// time instead of one by one.
+template <int R, bool CULL>
 __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const SweepArgs A)
 {
     __shared__ float4 tile[2][RT_APEX_PLANES][RT_TILE];
@@ -174,11 +227,105 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
     for (int r = 0; r < R; ++r)
         on_image |= ((px0 + COLS * r < A.W) && (lr < A.rows.rows) ? 1ull : 0ull) << r;
 
+    WaveRect rect{};
+    if constexpr (CULL) {
+        // columns wave_x0 .. the wave's last one on the image; rows: the image rows of the wave's
+        // local rows that exist (an interleaved row part maps them anywhere)
+        const int x_last = wave_x0 + COLS * R - 1 < A.W - 1 ? wave_x0 + COLS * R - 1 : A.W - 1;
+        const float xa = (float)(wave_x0 - A.W / 2), xb = (float)(x_last - A.W / 2);
+        float ya = lr < A.rows.rows ? Y : INF, yb = lr < A.rows.rows ? Y : -INF;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ya = __builtin_fminf(ya, __shfl_xor(ya, off));
+            yb = __builtin_fmaxf(yb, __shfl_xor(yb, off));
+        }
+        rect.x_c = 0.5f * (xa + xb);
+        rect.x_h = 0.5f * (xb - xa);
+        rect.xs_c = rect.x_c * (1.0f / COLS);
+        rect.xs_h = rect.x_h * (1.0f / COLS);
+        rect.y_c = 0.5f * (ya + yb);
+        rect.y_h = 0.5f * (yb - ya);
+    }
+
+    // One triangle against the R pixels of the lane: the sign tests of every pixel and, where one
+    // passes, the rest of the inside test.  cur = the triangle's planes 0 and 1, p = its plane 0
+    // in the LDS tile.
+    auto raster_triangle = [&](const Tri2& cur, const float4* __restrict__ p, int tri) {
+        // sign tests (k_pack_apex, sign layout): un = -(U + delta) and wn = -(W' + delta) of an
+        // orientation-normalised triangle are both negative exactly when the pixel is in the
+        // u slab, allowance included; their sign bits are and-ed per pixel and or-ed over
+        // the lane's pixels
+        const float yu = __builtin_fmaf(Y, cur.P.y, cur.P.z);
+        const float yw = __builtin_fmaf(Y, cur.Q.y, cur.Q.z);
+        float un = __builtin_fmaf(Xs0, cur.P.x, yu);
+        float wn = __builtin_fmaf(Xs0, cur.Q.x, yw);
+        int acc = __float_as_int(un) & __float_as_int(wn);
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+            if (r % 8 == 0) {       // a fresh start every 8 pixels bounds the rounding of the steps
+                un = __builtin_fmaf(Xs0 + (float)r, cur.P.x, yu);
+                wn = __builtin_fmaf(Xs0 + (float)r, cur.Q.x, yw);
+            } else {
+                un += cur.P.x;      // X / COLS grows by one from pixel to pixel
+                wn += cur.Q.x;
+            }
+            acc = and_or(un, wn, acc);
+        }
+        if (__builtin_expect(acc < 0, 0)) {
+            // Which pixels.  un and wn are linear along the lane's pixels, so the pixels where
+            // both are negative form one interval; its ends come from two divisions, and
+            // only the pixels inside it are evaluated again, each from its own X with the
+            // FMAs that decide (not kept in the hot loop).  The interval is a superset: a
+            // pixel whose FMA value is negative has a negative exact value, and the model
+            // u0 + r d differs from the exact value by the one rounding of u0.
+            const float u0 = __builtin_fmaf(Xs0, cur.P.x, yu), w0 = __builtin_fmaf(Xs0, cur.Q.x, yw);
+            float lo = 0.0f, hi = (float)(R - 1);
+            {
+                const float d = cur.P.x + 0.0f;         // -0 counts as +0
+                const float q = __builtin_fmaf(U22, __builtin_fabsf(u0), -u0) * __builtin_amdgcn_rcpf(d);
+                if (d < 0.0f) lo = __builtin_fmaxf(lo, q - 0.001f);      // r d < tol - u0  <=>  r > q
+                else hi = __builtin_fminf(hi, q + 0.001f);               //                 <=>  r < q
+            }
+            {
+                const float d = cur.Q.x + 0.0f;
+                const float q = __builtin_fmaf(U22, __builtin_fabsf(w0), -w0) * __builtin_amdgcn_rcpf(d);
+                if (d < 0.0f) lo = __builtin_fmaxf(lo, q - 0.001f);
+                else hi = __builtin_fminf(hi, q + 0.001f);
+            }
+            // (a NaN quotient leaves its bound alone: fmin / fmax return the other operand)
+            int r = (int)__builtin_ceilf(__builtin_fminf(lo, (float)R));
+            const int r_hi = (int)__builtin_floorf(__builtin_fmaxf(hi, -1.0f));
+#if RT_RASTER_CHECK_INTERVAL
+            {
+                unsigned long long pass = 0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const float Xs = Xs0 + (float)k;
+                    const float u1 = __builtin_fmaf(Xs, cur.P.x, yu);
+                    const float w1 = __builtin_fmaf(Xs, cur.Q.x, yw);
+                    pass |= (unsigned long long)((unsigned)(__float_as_int(u1) & __float_as_int(w1)) >> 31) << k;
+                }
+                const unsigned long long inside =
+                    r > r_hi ? 0ull : ((r_hi >= 63 ? ~0ull : (2ull << r_hi) - 1ull) & ~((1ull << r) - 1ull));
+                if ((pass & ~inside) && A.tests) atomicAdd(A.tests, 1ull << 48);
+            }
+#endif
+            for (; r <= r_hi; ++r) {
+                const float Xs = Xs0 + (float)r;
+                const float u1 = __builtin_fmaf(Xs, cur.P.x, yu);
+                const float w1 = __builtin_fmaf(Xs, cur.Q.x, yw);
+                if ((__float_as_int(u1) & __float_as_int(w1)) < 0 && ((on_image >> r) & 1ull))
+                    finish_raster(A, slot0 + COLS * r, tri, cur, p, Xs, Y, u1);
+            }
+        }
+    };
+
     // this workgroup's share of the triangle range: chunk blockIdx.y of gridDim.y
     const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
     const int t_begin = t_first + (int)((long)t_count * blockIdx.y / gridDim.y);
     const int t_end = t_first + (int)((long)t_count * (blockIdx.y + 1) / gridDim.y);
     unsigned long long tiles_done = 0;
+    unsigned kept = 0;              // tile culling: triangles that went on to the per-pixel tests
     if (t_begin < t_end) {
         stage_tile<RT_APEX_PLANES>(A.planes, A.plane_stride, t_begin, tile[0], wave, lane);
         __builtin_amdgcn_s_waitcnt(0);
@@ -190,79 +337,29 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
             stage_tile<RT_APEX_PLANES>(A.planes, A.plane_stride, t + 1, tile[buf ^ 1], wave, lane);
         const float4* __restrict__ base = tile[buf][0];
         const int tri0 = t * RT_TILE;
-        // LDS reads are issued one triangle ahead by hand (the rare path splits the body into
-        // basic blocks, which keeps the compiler from hoisting them)
-        Tri2 next = load_tri2(base);
-#pragma unroll kRasterUnroll
-        for (int j = 0; wave_on && j < RT_TILE; ++j) {
-            const Tri2 cur = next;
-            next = load_tri2(base + ((j + 1) & (RT_TILE - 1)));     // last iteration re-reads entry 0 (unused)
-            // sign tests (k_pack_apex, sign layout): un = -(U + delta) and wn = -(W' + delta) of an
-            // orientation-normalised triangle are both negative exactly when the pixel is in the
-            // u slab, allowance included; their sign bits are and-ed per pixel and or-ed over
-            // the lane's pixels
-            const float yu = __builtin_fmaf(Y, cur.P.y, cur.P.z);
-            const float yw = __builtin_fmaf(Y, cur.Q.y, cur.Q.z);
-            float un = __builtin_fmaf(Xs0, cur.P.x, yu);
-            float wn = __builtin_fmaf(Xs0, cur.Q.x, yw);
-            int acc = __float_as_int(un) & __float_as_int(wn);
+        if constexpr (CULL) {
+            static_assert(RT_TILE % 64 == 0, "one triangle per lane and round");
 #pragma unroll
-            for (int r = 1; r < R; ++r) {
-                if (r % 8 == 0) {       // a fresh start every 8 pixels bounds the rounding of the steps
-                    un = __builtin_fmaf(Xs0 + (float)r, cur.P.x, yu);
-                    wn = __builtin_fmaf(Xs0 + (float)r, cur.Q.x, yw);
-                } else {
-                    un += cur.P.x;      // X / COLS grows by one from pixel to pixel
-                    wn += cur.Q.x;
+            for (int h = 0; wave_on && h < RT_TILE / 64; ++h) {
+                const float4* mine = base + h * 64 + lane;
+                unsigned long long keep =
+                    __ballot(rect_may_hit(mine[0], mine[RT_TILE], mine[2 * RT_TILE], mine[3 * RT_TILE], rect));
+                kept += __popcll(keep);
+                while (keep) {
+                    const int j = h * 64 + __builtin_ctzll(keep);
+                    keep &= keep - 1;
+                    raster_triangle(load_tri2(base + j), base + j, tri0 + j);
                 }
-                acc = (__float_as_int(un) & __float_as_int(wn)) | acc;      // v_and_or_b32
             }
-            if (__builtin_expect(acc < 0, 0)) {
-                // Which pixels.  un and wn are linear along the lane's pixels, so the pixels where
-                // both are negative form one interval; its ends come from two divisions, and
-                // only the pixels inside it are evaluated again, each from its own X with the
-                // FMAs that decide (not kept in the hot loop).  The interval is a superset: a
-                // pixel whose FMA value is negative has a negative exact value, and the model
-                // u0 + r d differs from the exact value by the one rounding of u0.
-                const float u0 = __builtin_fmaf(Xs0, cur.P.x, yu), w0 = __builtin_fmaf(Xs0, cur.Q.x, yw);
-                float lo = 0.0f, hi = (float)(R - 1);
-                {
-                    const float d = cur.P.x + 0.0f;         // -0 counts as +0
-                    const float q = __builtin_fmaf(U22, __builtin_fabsf(u0), -u0) * __builtin_amdgcn_rcpf(d);
-                    if (d < 0.0f) lo = __builtin_fmaxf(lo, q - 0.001f);      // r d < tol - u0  <=>  r > q
-                    else hi = __builtin_fminf(hi, q + 0.001f);               //                 <=>  r < q
-                }
-                {
-                    const float d = cur.Q.x + 0.0f;
-                    const float q = __builtin_fmaf(U22, __builtin_fabsf(w0), -w0) * __builtin_amdgcn_rcpf(d);
-                    if (d < 0.0f) lo = __builtin_fmaxf(lo, q - 0.001f);
-                    else hi = __builtin_fminf(hi, q + 0.001f);
-                }
-                // (a NaN quotient leaves its bound alone: fmin / fmax return the other operand)
-                int r = (int)__builtin_ceilf(__builtin_fminf(lo, (float)R));
-                const int r_hi = (int)__builtin_floorf(__builtin_fmaxf(hi, -1.0f));
-#if RT_RASTER_CHECK_INTERVAL
-                {
-                    unsigned long long pass = 0;
-#pragma unroll
-                    for (int k = 0; k < R; ++k) {
-                        const float Xs = Xs0 + (float)k;
-                        const float u1 = __builtin_fmaf(Xs, cur.P.x, yu);
-                        const float w1 = __builtin_fmaf(Xs, cur.Q.x, yw);
-                        pass |= (unsigned long long)((unsigned)(__float_as_int(u1) & __float_as_int(w1)) >> 31) << k;
-                    }
-                    const unsigned long long inside =
-                        r > r_hi ? 0ull : ((r_hi >= 63 ? ~0ull : (2ull << r_hi) - 1ull) & ~((1ull << r) - 1ull));
-                    if ((pass & ~inside) && A.tests) atomicAdd(A.tests, 1ull << 48);
-                }
-#endif
-                for (; r <= r_hi; ++r) {
-                    const float Xs = Xs0 + (float)r;
-                    const float u1 = __builtin_fmaf(Xs, cur.P.x, yu);
-                    const float w1 = __builtin_fmaf(Xs, cur.Q.x, yw);
-                    if ((__float_as_int(u1) & __float_as_int(w1)) < 0 && ((on_image >> r) & 1ull))
-                        finish_raster(A, slot0 + COLS * r, tri0 + j, cur, base + j, Xs, Y, u1);
-                }
+        } else {
+            // LDS reads are issued one triangle ahead by hand (the rare path splits the body into
+            // basic blocks, which keeps the compiler from hoisting them)
+            Tri2 next = load_tri2(base);
+#pragma unroll kRasterUnroll
+            for (int j = 0; wave_on && j < RT_TILE; ++j) {
+                const Tri2 cur = next;
+                next = load_tri2(base + ((j + 1) & (RT_TILE - 1)));     // last iteration re-reads entry 0 (unused)
+                raster_triangle(cur, base + j, tri0 + j);
             }
         }
         ++tiles_done;
@@ -270,8 +367,9 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
         __syncthreads();
     }
 
+    // pairs tested one by one: all of them, or with tile culling those of the surviving triangles
     if (A.tests && lane == 0 && wave_on)
-        atomicAdd(A.tests, tiles_done * (unsigned long long)RT_TILE * (64 * R));
+        atomicAdd(A.tests, (CULL ? (unsigned long long)kept : tiles_done * (unsigned long long)RT_TILE) * (64 * R));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -384,12 +482,80 @@ __device__ __forceinline__ bool finish_apex(const SweepArgs& A, float u, float v
 // such ray.  The slab passes are therefore handled lane-wise: every lane picks its first passing
 // ray (a chain of selects), the wave finishes those together, and the loop repeats only while
 // some lane has another one.
-template <int AX, int R>
+// The (u, v) bounding box of a wave's live rays, for the tile-culling variant.
+struct WaveBox { float u_c, u_h, v_c, v_h; };
+
+// Centre value and radius over the box of the dot product D'.p for D' of dominant axis AX.
+template <int AX>
+__device__ __forceinline__ void box_range(const float4& p, const WaveBox& b, float& lo, float& hi)
+{
+    const float cu = AX == 0 ? p.y : p.x, cv = AX == 2 ? p.y : p.z;
+    const float c = dot_ax<AX>(b.u_c, b.v_c, p);
+    const float r = __builtin_fmaf(__builtin_fabsf(cu), b.u_h, __builtin_fabsf(cv) * b.v_h) * 1.000001f;
+    lo = c - r;
+    hi = c + r;
+}
+
+// Can any ray of the box hit this triangle?  For a hit U, W' = det - U, V and W' - V all have the
+// sign of det (0 <= u <= 1, v >= 0, u + v <= 1).  Each is a dot product with D' and therefore
+// affine in (u, v): over the box it stays within its centre value +- (|du| hu + |dv| hv).  The
+// triangle is dropped only when one of the four is negative and another positive over the whole
+// box, each by twice the margin m = 32 delta of the per-ray inside test -- far more than the
+// rounding of these few fp32 operations, which is a few 2^-24 of the magnitudes delta is 2^-20
+// of.  NaN or infinite entries (m = +inf marks a nearly degenerate triangle) make the
+// comparisons false: the triangle is kept and the per-ray tests decide.
+template <int AX>
+__device__ __forceinline__ bool box_may_hit(const float4& P, const float4& Q, const float4& Hh, const WaveBox& b)
+{
+    const float s = 2.0f * Q.w;
+    float lo, hi;
+    box_range<AX>(P, b, lo, hi);
+    bool neg = hi < -s, pos = lo > s;
+    box_range<AX>(Q, b, lo, hi);
+    neg = neg || hi < -s;
+    pos = pos || lo > s;
+    box_range<AX>(Hh, b, lo, hi);
+    neg = neg || hi < -s;
+    pos = pos || lo > s;
+    const float4 G = make_float4(Q.x - Hh.x, Q.y - Hh.y, Q.z - Hh.z, 0.0f);     // W' - V
+    box_range<AX>(G, b, lo, hi);
+    neg = neg || hi < -s;
+    pos = pos || lo > s;
+    return !(neg && pos);
+}
+
+template <int R>
+__device__ __forceinline__ WaveBox wave_box(const ApexRay (&ray)[R])
+{
+    // retired and unused rays carry NaN, which fmin / fmax pass over
+    float u0 = INF, u1 = -INF, v0 = INF, v1 = -INF;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        u0 = __builtin_fminf(u0, ray[r].u);
+        u1 = __builtin_fmaxf(u1, ray[r].u);
+        v0 = __builtin_fminf(v0, ray[r].u == ray[r].u ? ray[r].v : INF);
+        v1 = __builtin_fmaxf(v1, ray[r].u == ray[r].u ? ray[r].v : -INF);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        u0 = __builtin_fminf(u0, __shfl_xor(u0, off));
+        u1 = __builtin_fmaxf(u1, __shfl_xor(u1, off));
+        v0 = __builtin_fminf(v0, __shfl_xor(v0, off));
+        v1 = __builtin_fmaxf(v1, __shfl_xor(v1, off));
+    }
+    // (a wave without live rays gets infinite centres: every comparison is false, but then
+    // no ray passes a slab test either)
+    return {0.5f * (u0 + u1), 0.5f * (u1 - u0), 0.5f * (v0 + v1), 0.5f * (v1 - v0)};
+}
+
+template <int AX, int R, bool CULL>
 __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT_APEX_PLANES][RT_TILE],
                                            ApexRay (&ray)[R], long j0, int wave, int lane,
-                                           unsigned long long& tiles_done)
+                                           unsigned long long& tiles_done, unsigned& kept)
 {
     const float qnan = __builtin_nanf("");
+    WaveBox box{};
+    if constexpr (CULL) box = wave_box<R>(ray);
     // this workgroup's share of the triangle range: chunk blockIdx.z of gridDim.z
     const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
     const int t_begin = t_first + (int)((long)t_count * blockIdx.z / gridDim.z);
@@ -405,11 +571,8 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
             stage_tile<RT_APEX_PLANES>(A.planes, A.plane_stride, t + 1, tile[buf ^ 1], wave, lane);
         const float4* __restrict__ base = tile[buf][0];
         const int tri0 = t * RT_TILE;
-        Tri2 next = load_tri2(base);
-#pragma unroll kApexUnroll
-        for (int j = 0; j < RT_TILE; ++j) {
-            const Tri2 cur = next;
-            next = load_tri2(base + ((j + 1) & (RT_TILE - 1)));
+        // one triangle (entry j of the tile) against the lane's R rays
+        auto apex_triangle = [&](const Tri2& cur, int j) {
             // U * W' >= -c, with the product as a plain multiplication (a two-operand
             // instruction: cheaper to issue and on power than the FMA with c; its one rounding
             // is far inside the 0.1 % by which c exceeds the bound it stands for)
@@ -444,6 +607,31 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
                     }
                 }
             }
+        };
+        if constexpr (CULL) {
+            // every lane tests one triangle of the tile against the wave's whole bundle; only
+            // the survivors meet the rays one by one
+            static_assert(RT_TILE % 64 == 0, "one triangle per lane and round");
+            if (((t - t_begin) & 15) == 15) box = wave_box<R>(ray);     // the bundle shrinks as rays retire
+#pragma unroll
+            for (int h = 0; h < RT_TILE / 64; ++h) {
+                const float4* mine = base + h * 64 + lane;
+                unsigned long long keep = __ballot(box_may_hit<AX>(mine[0], mine[RT_TILE], mine[2 * RT_TILE], box));
+                kept += __popcll(keep);
+                while (keep) {
+                    const int j = h * 64 + __builtin_ctzll(keep);
+                    keep &= keep - 1;
+                    apex_triangle(load_tri2(base + j), j);
+                }
+            }
+        } else {
+            Tri2 next = load_tri2(base);
+#pragma unroll kApexUnroll
+            for (int j = 0; j < RT_TILE; ++j) {
+                const Tri2 cur = next;
+                next = load_tri2(base + ((j + 1) & (RT_TILE - 1)));
+                apex_triangle(cur, j);
+            }
         }
         ++tiles_done;
         __builtin_amdgcn_s_waitcnt(0);
@@ -468,7 +656,7 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
 // the n = live_counts[s] ray numbers active[s * light_ray_stride ...]; the rays, counts and
 // lists of light l start l * light_ray_stride rays into their arrays, its planes
 // l * light_plane_stride float4 into theirs.
-template <int R>
+template <int R, bool CULL>
 __global__ void __launch_bounds__(RT_WG, R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
 {
     __shared__ float4 tile[2][RT_APEX_PLANES][RT_TILE];
@@ -525,14 +713,19 @@ __global__ void __launch_bounds__(RT_WG, R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES)
     }
 
     unsigned long long tiles_done = 0;
+    unsigned kept = 0;      // tile culling: triangles that met this wave's rays one by one
     switch (axis) {         // uniform over the workgroup
-    case 0: apex_tiles<0, R>(A, tile, ray, j0, wave, lane, tiles_done); break;
-    case 1: apex_tiles<1, R>(A, tile, ray, j0, wave, lane, tiles_done); break;
-    default: apex_tiles<2, R>(A, tile, ray, j0, wave, lane, tiles_done); break;
+    case 0: apex_tiles<0, R, CULL>(A, tile, ray, j0, wave, lane, tiles_done, kept); break;
+    case 1: apex_tiles<1, R, CULL>(A, tile, ray, j0, wave, lane, tiles_done, kept); break;
+    default: apex_tiles<2, R, CULL>(A, tile, ray, j0, wave, lane, tiles_done, kept); break;
     }
 
-    if (A.tests && tid == 0)
+    // pairs tested one by one: all of them, or with tile culling those of each wave's survivors
+    if (CULL) {
+        if (A.tests && lane == 0) atomicAdd(A.tests, (unsigned long long)kept * (64 * R));
+    } else if (A.tests && tid == 0) {
         atomicAdd(A.tests, tiles_done * (unsigned long long)RT_TILE * (RT_WG * R));
+    }
 }
 
 // Bins the shadow rays of every light by the dominant axis of their direction: ray numbers
@@ -718,7 +911,9 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
             return;
         }
     }
-    int r = RT_RASTER_RPL;
+    // (with tile culling a wave's pixel rectangle should not be too wide: the narrower, the fewer
+    // triangles survive its test; 32 pixels per lane measured best on a 1 M-triangle 4K frame)
+    int r = rt_tile_culling() && RT_RASTER_RPL > 32 ? 32 : RT_RASTER_RPL;
     while (r > 1 && RT_RASTER_COLS * r > W + RT_RASTER_COLS * r / 2) r /= 2;    // no wave mostly off the image
     // more pixels per lane cost fewer instructions per pair, but their wider tiles may cover
     // more pixels beyond the image's edges: take the cheaper product
@@ -768,21 +963,26 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
         return RT_E_ARG;
     }
     const dim3 grid((unsigned)rt_raster_tiles(a.W, a.rows.rows, r, wx), chunks);
+#define RT_RASTER_CASE(n)                                                                          \
+    case n:                                                                                        \
+        return a.cull ? launch(k_sweep_raster<n, true>, a, grid, st, "raster sweep (tile culling)") \
+                      : launch(k_sweep_raster<n, false>, a, grid, st, "raster sweep");
     switch (r) {
-    case 1: return launch(k_sweep_raster<1>, a, grid, st, "raster sweep");
-    case 2: return launch(k_sweep_raster<2>, a, grid, st, "raster sweep");
-    case 4: return launch(k_sweep_raster<4>, a, grid, st, "raster sweep");
-    case 8: return launch(k_sweep_raster<8>, a, grid, st, "raster sweep");
+        RT_RASTER_CASE(1)
+        RT_RASTER_CASE(2)
+        RT_RASTER_CASE(4)
+        RT_RASTER_CASE(8)
 #if RT_RASTER_RPL >= 16
-    case 16: return launch(k_sweep_raster<16>, a, grid, st, "raster sweep");
+        RT_RASTER_CASE(16)
 #endif
 #if RT_RASTER_RPL >= 32
-    case 32: return launch(k_sweep_raster<32>, a, grid, st, "raster sweep");
+        RT_RASTER_CASE(32)
 #endif
 #if RT_RASTER_RPL >= 64
-    case 64: return launch(k_sweep_raster<64>, a, grid, st, "raster sweep");
+        RT_RASTER_CASE(64)
 #endif
     }
+#undef RT_RASTER_CASE
     rt_set_error("raster sweep: unsupported pixels per lane %d", r);
     return RT_E_ARG;
 }
@@ -853,14 +1053,19 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
     const unsigned wgs = (unsigned)((a.n_rays + per_wg - 1) / per_wg);
     const long all_wgs = (shape_rays + per_wg - 1) / per_wg + a.lights;
     const dim3 grid(wgs, a.lights, forced_chunks ? forced_chunks : apex_chunks(all_wgs, max_chunks));
+#define RT_APEX_CASE(n)                                                                        \
+    case n:                                                                                    \
+        return a.cull ? launch(k_sweep_apex<n, true>, a, grid, st, "apex sweep (tile culling)") \
+                      : launch(k_sweep_apex<n, false>, a, grid, st, "apex sweep");
     switch (r) {
-    case 1: return launch(k_sweep_apex<1>, a, grid, st, "apex sweep");
-    case 2: return launch(k_sweep_apex<2>, a, grid, st, "apex sweep");
-    case 4: return launch(k_sweep_apex<4>, a, grid, st, "apex sweep");
+        RT_APEX_CASE(1)
+        RT_APEX_CASE(2)
+        RT_APEX_CASE(4)
 #if RT_APEX_RPL > 4
-    case RT_APEX_RPL: return launch(k_sweep_apex<RT_APEX_RPL>, a, grid, st, "apex sweep");
+        RT_APEX_CASE(RT_APEX_RPL)
 #endif
     }
+#undef RT_APEX_CASE
     rt_set_error("apex sweep: unsupported rays per lane %d", r);
     return RT_E_ARG;
 }

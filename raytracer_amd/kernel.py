@@ -369,6 +369,15 @@ class MultiScene:
             pass
 
 
+def set_tile_culling(on) -> None:
+    """rt_set_tile_culling: True / False, or None to follow RT_AMD_CULL again."""
+    check(_lib.load().rt_set_tile_culling(-1 if on is None else (1 if on else 0)))
+
+
+def tile_culling() -> bool:
+    return bool(_lib.load().rt_get_tile_culling())
+
+
 def profile_enable(on: bool = True) -> None:
     check(_lib.load().rt_profile_enable(1 if on else 0))
 
