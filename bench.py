@@ -277,9 +277,31 @@ def main() -> None:
     prof = kernel.profile_get()
     kernel.profile_enable(False)
 
+    # The same steps once more with the library's tile culling on (off by default: the headline
+    # is the all-pairs sweep).  Every wave still visits every triangle, but tests a tile's
+    # triangles against its whole bundle of rays first; the pictures must be identical.
+    dt_culled, culled_same = 0.0, None
+    culling_was_on = kernel.tile_culling()
+    if not culling_was_on:
+        plain_screen = screen.clone() if (screen is not None and not sequence) else None
+        kernel.set_tile_culling(True)
+        profiled[0] = False
+        step_no[0] -= 1 if not sequence else 0
+        step()                                    # warm-up: the culled kernels' first launch
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_no[0] -= 1 if not sequence else 0
+            step()
+        fence()
+        dt_culled = time.perf_counter() - t0
+        kernel.set_tile_culling(None)
+        if plain_screen is not None:
+            culled_same = bool(torch.equal(plain_screen, screen))
+
     stats = torch.tensor([dt, float(prof.rays_primary), float(prof.rays_shadow), float(prof.sweep_tests),
                           float(prof.shadow_tests), prof.sweep_ms, float(prof.sweep_launches),
-                          prof.shadow_ms, float(prof.exact_candidates), float(prof.exact_overflow)],
+                          prof.shadow_ms, float(prof.exact_candidates), float(prof.exact_overflow), dt_culled],
                          dtype=torch.float64, device=dev)
     tmax = stats.clone()
     tsum = stats.clone()
@@ -394,6 +416,19 @@ def main() -> None:
                 },
             },
         }
+        if culling_was_on:
+            res["config"]["tile_culling"] = "on for the whole run (RT_AMD_CULL): the figures above are not the all-pairs sweep's"
+        else:
+            wall_c = tmax[10].item()
+            res["tile_culling"] = {
+                "what": "the same steps with rt_set_tile_culling(1): a tile's triangles are tested against a wave's "
+                        "whole ray bundle before the per-ray tests; off by default, not part of `value`",
+                "ms_per_step": wall_c / steps * 1e3,
+                "value": (rays_p + rays_s) / (wall_c / steps) / 1e6, "unit": "Mrays/s",
+                "frames_per_s": steps * (world if frame_parallel else 1) / wall_c,
+                "speedup_vs_all_pairs": wall / wall_c if wall_c > 0 else None,
+                "screen_identical_to_all_pairs": culled_same,
+            }
         if single:
             # the picture the devices assembled against the profiled single-scene render of the same frame
             res["verify"] = {"screen_equals_single_rank_render": bool(torch.equal(single_screen, screen))}
