@@ -117,7 +117,7 @@ def mix_alone(name: str, tests_per_s: float) -> dict:
     return {}
 
 
-ROCPROF_DIR = "profiles/r02_bench_soup1m_4k"     # tools/profile_bench.sh over this program's default run
+ROCPROF_DIR = "profiles/r02b_bench_soup1m_4k"     # tools/profile_bench.sh over this program's default run
 
 
 def rocprof_avg_ms(workload: str, kernel_prefix: str) -> dict | None:
@@ -276,6 +276,15 @@ def main() -> None:
     fence()
     prof = kernel.profile_get()
     kernel.profile_enable(False)
+    # the shape and instruction mix of that frame's sweeps (the library reports its most recent launch)
+    import ctypes as C
+    from raytracer_amd import _lib
+    tile, ppl, spl, chunks = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    f_primary, f_shadow = C.c_double(), C.c_double()
+    _lib.load().rt_apex_sweep_config(C.byref(tile), C.byref(ppl), C.byref(f_primary), C.byref(spl),
+                                     C.byref(f_shadow), C.byref(chunks))
+    mix = [C.c_int() for _ in range(5)]
+    _lib.load().rt_raster_sweep_mix(*[C.byref(m) for m in mix])
 
     # The same steps once more with the library's tile culling on (off by default: the headline
     # is the all-pairs sweep).  Every wave still visits every triangle, but tests a tile's
@@ -318,26 +327,18 @@ def main() -> None:
         # roofline of the dominant kernel: rank 0's closest-hit sweep launch of the profiled frame
         sweep_ms_avg = prof.sweep_ms / max(prof.sweep_launches, 1)
         tests_per_launch = prof.sweep_tests / max(prof.sweep_launches, 1)
-        import ctypes as C
-        from raytracer_amd import _lib
-        tile, ppl, spl, chunks = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        f_primary, f_shadow = C.c_double(), C.c_double()
-        _lib.load().rt_apex_sweep_config(C.byref(tile), C.byref(ppl), C.byref(f_primary), C.byref(spl),
-                                         C.byref(f_shadow), C.byref(chunks))
         f_exec = f_primary.value                  # flops the hot loop really executes per pair
-        mix = [C.c_int() for _ in range(5)]
-        _lib.load().rt_raster_sweep_mix(*[C.byref(m) for m in mix])
         mix_ppl, n_fma, n_add, n_logic, n_cmp = [m.value for m in mix]
         instr_per_test = (n_fma + n_add + n_logic + n_cmp) / mix_ppl
         tests_per_s_launch = tests_per_launch / (sweep_ms_avg * 1e-3) if sweep_ms_avg > 0 else 0.0
         achieved = tests_per_s_launch * f_exec / 1e12
         traffic = measured_traffic(args.workload, f"raster-tile{tile.value}-ppl{ppl.value}-chunks{chunks.value}") if world == 1 else None
-        rp = rocprof_avg_ms(args.workload, f"k_sweep_raster<{ppl.value}>") if world == 1 else None
+        rp = rocprof_avg_ms(args.workload, f"k_sweep_raster<{ppl.value}, false>") if world == 1 else None
         # the any-hit sweeps of the shadow rays: a third of the frame
         sh_ms, sh_tests = prof.shadow_ms, float(prof.shadow_tests)
         sh_rate = sh_tests / (sh_ms * 1e-3) if sh_ms > 0 else 0.0
         sh_instr = 45.0 / 8.0                     # hot loop: 45 VALU instructions per 8 pairs (rocprof: 6.08 with the rare path)
-        rp_sh = rocprof_avg_ms(args.workload, f"k_sweep_apex<{spl.value}>") if world == 1 else None
+        rp_sh = rocprof_avg_ms(args.workload, f"k_sweep_apex<{spl.value}, false>") if world == 1 else None
         res = {
             "metric": "Mrays/s and ray-tri tests/s (% fp32 peak) at 1/2/4/8 MI355X vs host-CPU ref",
             "value": (rays_p + rays_s) / (wall / steps) / 1e6,
@@ -376,7 +377,7 @@ def main() -> None:
             # kernel is to the machine's limit, and the stated target of half the fp32 flop peak is
             # not met by construction.
             "roofline": {
-                "bound": "valu-fp32", "kernel": f"k_sweep_raster<{ppl.value}> (primary rays, closest hit)",
+                "bound": "valu-fp32", "kernel": f"k_sweep_raster<{ppl.value}, false> (primary rays, closest hit, all pairs)",
                 "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS,
                 "target_50pct_fp32_flops_met": bool(achieved / PEAK_FP32_TFLOPS >= 0.5),
@@ -401,7 +402,7 @@ def main() -> None:
                                  "triangle_chunks": chunks.value},
                 # second kernel: the any-hit sweeps (rank 0, all launches of the profiled frame)
                 "anyhit": {
-                    "kernel": f"k_sweep_apex<{spl.value}> (shadow rays, any hit)",
+                    "kernel": f"k_sweep_apex<{spl.value}, false> (shadow rays, any hit, all pairs)",
                     "ms_per_frame": sh_ms, "launches_per_frame": int(prof.shadow_launches),
                     "tests_per_frame": sh_tests, "tests_per_s": sh_rate,
                     "flop_per_test": f_shadow.value,

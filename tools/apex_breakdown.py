@@ -16,7 +16,7 @@ tot = collections.defaultdict(float)
 for r, t in zip(disp, tests):
     c = ctr[r["Dispatch_Id"]]
     ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-    name = re.search(r"k_sweep_apex<\d+>", r["Kernel_Name"]).group(0)
+    name = re.search(r"k_sweep_apex<\d+(, (false|true))?>", r["Kernel_Name"]).group(0)
     grid = f"{int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])}x{r['Grid_Size_Y']}x{r['Grid_Size_Z']}"
     ghz = c["GRBM_GUI_ACTIVE"] / (ms * 1e-3) / 1e9 if "GRBM_GUI_ACTIVE" in c else float("nan")
     # issue slots: one VALU instruction per SIMD every two cycles = 1024 SIMDs x clock / 2 wave-instructions/s

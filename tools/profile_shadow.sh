@@ -13,12 +13,12 @@ root = sys.argv[1]
 tot = collections.defaultdict(float); n = 0
 for f in glob.glob(root + "/*/vm/*_counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        if "k_sweep_apex" in row["Kernel_Name"]:
+        if "k_sweep_apex" in row["Kernel_Name"] and "false>" in row["Kernel_Name"]:     # the all-pairs launches
             tot[row["Counter_Name"]] += float(row["Counter_Value"])
 dur = 0.0; launches = 0
 f = glob.glob(root + "/pmc_issue/vm/*_kernel_trace.csv")[0]
 for row in csv.DictReader(open(f)):
-    if "k_sweep_apex" in row["Kernel_Name"]:
+    if "k_sweep_apex" in row["Kernel_Name"] and "false>" in row["Kernel_Name"]:
         dur += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9; launches += 1
 line = [l for l in open(root + "/pmc_issue.log") if l.startswith('{"metric')][0]
 d = json.loads(line)
