@@ -933,19 +933,20 @@ static int trace_rays_impl(rt_scene* sc, const RayWorkspace* static_ws, int n, c
 static int prepare_lights(rt_scene* sc, const rt_frame* f, int l0, int lights, hipStream_t st)
 {
     static const bool sort_tris = !(getenv("RT_AMD_SORT_TRIS") && atoi(getenv("RT_AMD_SORT_TRIS")) == 0);
-    const size_t set_planes = (size_t)RT_APEX_PLANES * sc->num_tris_padded;
+    const size_t set_planes = (size_t)RT_LIGHT_PLANES * sc->num_tris_padded;
     for (int k = 0; k < lights; ++k) {
         int32_t* ord = sort_tris ? sc->tri_order.as<int32_t>() + (size_t)k * sc->num_tris_padded : nullptr;
         if (ord) RT_TRY(rt_launch_sort_triangles(sc, f->light_in_eye_space[l0 + k], ord, st));
-        RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l0 + k], 1.0, 1.75,
-                                   sc->planes_light.as<float4>() + k * set_planes, false, ord, st));
+        float4* dst = sc->planes_light.as<float4>() + k * set_planes;
+        RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l0 + k], 1.0, 1.75, dst, false, ord, st,
+                                   dst + (size_t)RT_APEX_PLANES * sc->num_tris_padded));
     }
     return RT_OK;
 }
 
 static int reserve_light_buffers(rt_scene* sc, int lights)
 {
-    RT_TRY(sc->planes_light.reserve(sizeof(float4) * (size_t)sc->num_tris_padded * RT_APEX_PLANES * lights));
+    RT_TRY(sc->planes_light.reserve(sizeof(float4) * (size_t)sc->num_tris_padded * RT_LIGHT_PLANES * lights));
     RT_TRY(sc->tri_order.reserve(sizeof(int32_t) * (size_t)sc->num_tris_padded * lights));
     return RT_OK;
 }
@@ -1010,7 +1011,7 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
         a.cull = rt_tile_culling() ? 1 : 0;
         a.tri_order = order;
         a.planes = sc->planes_light.as<float4>(); a.plane_stride = sc->num_tris_padded;
-        a.light_plane_stride = (long)RT_APEX_PLANES * sc->num_tris_padded;
+        a.light_plane_stride = (long)RT_LIGHT_PLANES * sc->num_tris_padded;
         a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
         a.S = S + 3 * npix * (size_t)l0; a.E = E + 3 * npix * (size_t)l0;
         a.cnt = sc->ws_cnt.as<int32_t>() + npix * (size_t)l0;

@@ -73,12 +73,15 @@ constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
 #define RT_APEX_RPL 8       // rays per lane of the any-hit apex sweep
 #endif
 constexpr int RT_APEX_PLANES = 4;
+// a light's plane set: the four apex planes and the bounding squares for the three dominant axes
+constexpr int RT_LIGHT_PLANES = RT_APEX_PLANES + 3;
 constexpr int RT_APEX_LIGHTS = 4;   // lights swept per any-hit launch (plane sets kept side by side)
 constexpr int RT_APEX_SETS = 3 * RT_APEX_LIGHTS;    // ray sets per launch: light x dominant axis
 // Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels): 2 FMA for the row terms,
 // 2 FMA for the first pixel of every 8, 2 additions for each further pixel, then per pixel one
-// logic instruction on the two sign bits, and one compare.  Apex sweep, per pair: two dot products
-// with a unit dominant component (2 FMA each) + 1 FMA.
+// logic instruction on the two sign bits, and one compare.  Any-hit apex sweep, per pair: two
+// subtractions and a maximum (the bounding-square test), a three-way minimum per two pairs and a
+// compare per eight: 29 instructions per 8 pairs, 2 flops per pair.
 struct RasterMix { int fma, add, logic, compare; };
 constexpr RasterMix rt_raster_mix(int rpl)
 {
@@ -89,7 +92,8 @@ constexpr double rt_raster_flop_per_pair(int rpl)
 {
     return (2.0 * rt_raster_mix(rpl).fma + rt_raster_mix(rpl).add) / rpl;
 }
-constexpr double RT_APEX_FLOP_PER_PAIR = 9.0;
+constexpr double RT_APEX_FLOP_PER_PAIR = 2.0;
+constexpr double RT_APEX_INSTR_PER_PAIR = 29.0 / 8.0;
 
 // per-ray candidate counter written by the sweep: low bits = candidates pushed, plus
 constexpr int RT_CNT_OCCLUDED = 0x40000000;   // any-hit: a certain hit was found
@@ -195,8 +199,10 @@ int rt_launch_transform(const double* m16, const double* x, const double* y, con
 int rt_launch_pack(rt_scene* sc, hipStream_t st);
 // apex planes for rays through `apex`; zs is folded into the z components (the constant z of
 // pixel-grid directions, 1 otherwise); dmax bounds |D| of every ray of the sweep
+// squares (or nullptr): three more planes of num_tris_padded entries, the bounding squares of the
+// any-hit sweep's first test for the dominant axes 0, 1, 2 (product layout only)
 int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, float4* dst,
-                        bool sign_layout, const int32_t* order, hipStream_t st);
+                        bool sign_layout, const int32_t* order, hipStream_t st, float4* squares = nullptr);
 // into the RT_APEX_PLANES planes of num_tris_padded entries at dst; order (or nullptr): entry k
 // holds triangle order[k]
 

@@ -8,18 +8,21 @@
 // vanishes when the triangle is expressed relative to the shared point P, and the three
 // determinants become plain dot products of the ray direction with per-triangle vectors
 // (k_pack_apex, rt_transform.hip):   U = D.p   W' = det - U = D.q   V = D.h   det = D.nn.
-// A pair lies in the u slab (0 <= u <= 1) exactly when U and W' have the sign of det.  That is
-// the first test of a pair in both kernels; the rare path behind it finishes the inside test
-// (V, det, the v and u+v edges, the ray parameter) and appends survivors to the ray's candidate
-// list; the fp64 pass of rt_exact.hip then decides with the reference's exact arithmetic.
+// Every (ray, triangle) pair first meets a cheap conservative test (the u slab 0 <= u <= 1 for
+// the pixel grid, a bounding square for the shadow rays); the rare path behind it finishes the
+// inside test (U, V, det, the three edges, the ray parameter) and appends survivors to the ray's
+// candidate list; the fp64 pass of rt_exact.hip then decides with the reference's exact
+// arithmetic.
 //
-//   k_sweep_apex    any-hit, for the shadow rays of up to four lights.  Since U + W' = det, the
-//                   slab is U * W' >= 0: per pair  U * W' >= -c  with c the per-triangle
-//                   rounding allowance that makes the fp32 test a conservative filter
-//                   (derivation at k_pack_apex), rare path when it holds.  Directions are scaled to
-//                   a unit dominant component (rays binned by that axis, k_bin_rays), so a dot
-//                   product is two FMAs: 4 FMA, a multiplication and the comparison = 5.6 VALU instructions
-//                   per pair.
+//   k_sweep_apex    any-hit, for the shadow rays of up to four lights.  Directions are scaled to
+//                   a unit dominant component, D' = D / D_k (rays binned by that axis,
+//                   k_bin_rays), i.e. a ray is the point (u, v) on the plane D_k = 1 through
+//                   P, and it can only hit a triangle whose central projection onto that plane
+//                   contains (u, v).  First test of a pair: (u, v) inside the projection's
+//                   bounding square (k_pack_apex writes one per triangle and axis, allowances
+//                   included): two subtractions and a maximum, 3.6 VALU instructions per pair
+//                   with the reduction over a lane's rays.  The rare path behind it is the
+//                   full inside test on the four dot products.
 //                   Triangles in the order of their solid angle at the light, triangle ranges
 //                   with survivor compaction in between, triangle chunks that share a ray's
 //                   state through atomics, an occluder cache in front (host side:
@@ -39,7 +42,7 @@
 #include "rt_sweep_common.h"
 
 #ifndef RT_APEX8_WAVES
-#define RT_APEX8_WAVES 5    // waves per SIMD the 8-rays-per-lane any-hit kernel must fit
+#define RT_APEX8_WAVES 6    // waves per SIMD the 8-rays-per-lane any-hit kernel must fit
 #endif
 #ifndef RT_APEX_POLL
 #define RT_APEX_POLL 16     // tiles between looks at the flags other chunks may have set (power of two)
@@ -49,6 +52,9 @@
 #endif
 #ifndef RT_APEX_UNROLL
 #define RT_APEX_UNROLL 4
+#endif
+#ifndef RT_CULL_GROUP
+#define RT_CULL_GROUP 4     // tiles whose bounding squares the culled any-hit sweep stages at a time
 #endif
 #ifndef RT_RASTER_UNROLL
 #define RT_RASTER_UNROLL 4
@@ -485,45 +491,6 @@ __device__ __forceinline__ bool finish_apex(const SweepArgs& A, float u, float v
 // The (u, v) bounding box of a wave's live rays, for the tile-culling variant.
 struct WaveBox { float u_c, u_h, v_c, v_h; };
 
-// Centre value and radius over the box of the dot product D'.p for D' of dominant axis AX.
-template <int AX>
-__device__ __forceinline__ void box_range(const float4& p, const WaveBox& b, float& lo, float& hi)
-{
-    const float cu = AX == 0 ? p.y : p.x, cv = AX == 2 ? p.y : p.z;
-    const float c = dot_ax<AX>(b.u_c, b.v_c, p);
-    const float r = __builtin_fmaf(__builtin_fabsf(cu), b.u_h, __builtin_fabsf(cv) * b.v_h) * 1.000001f;
-    lo = c - r;
-    hi = c + r;
-}
-
-// Can any ray of the box hit this triangle?  For a hit U, W' = det - U, V and W' - V all have the
-// sign of det (0 <= u <= 1, v >= 0, u + v <= 1).  Each is a dot product with D' and therefore
-// affine in (u, v): over the box it stays within its centre value +- (|du| hu + |dv| hv).  The
-// triangle is dropped only when one of the four is negative and another positive over the whole
-// box, each by twice the margin m = 32 delta of the per-ray inside test -- far more than the
-// rounding of these few fp32 operations, which is a few 2^-24 of the magnitudes delta is 2^-20
-// of.  NaN or infinite entries (m = +inf marks a nearly degenerate triangle) make the
-// comparisons false: the triangle is kept and the per-ray tests decide.
-template <int AX>
-__device__ __forceinline__ bool box_may_hit(const float4& P, const float4& Q, const float4& Hh, const WaveBox& b)
-{
-    const float s = 2.0f * Q.w;
-    float lo, hi;
-    box_range<AX>(P, b, lo, hi);
-    bool neg = hi < -s, pos = lo > s;
-    box_range<AX>(Q, b, lo, hi);
-    neg = neg || hi < -s;
-    pos = pos || lo > s;
-    box_range<AX>(Hh, b, lo, hi);
-    neg = neg || hi < -s;
-    pos = pos || lo > s;
-    const float4 G = make_float4(Q.x - Hh.x, Q.y - Hh.y, Q.z - Hh.z, 0.0f);     // W' - V
-    box_range<AX>(G, b, lo, hi);
-    neg = neg || hi < -s;
-    pos = pos || lo > s;
-    return !(neg && pos);
-}
-
 template <int R>
 __device__ __forceinline__ WaveBox wave_box(const ApexRay (&ray)[R])
 {
@@ -543,112 +510,211 @@ __device__ __forceinline__ WaveBox wave_box(const ApexRay (&ray)[R])
         v0 = __builtin_fminf(v0, __shfl_xor(v0, off));
         v1 = __builtin_fmaxf(v1, __shfl_xor(v1, off));
     }
-    // (a wave without live rays gets infinite centres: every comparison is false, but then
-    // no ray passes a slab test either)
+    // (a wave without live rays gets infinite centres and NaN extents: every comparison is
+    // false and nothing is kept, but then no ray could pass a test either)
     return {0.5f * (u0 + u1), 0.5f * (u1 - u0), 0.5f * (v0 + v1), 0.5f * (v1 - v0)};
 }
 
-template <int AX, int R, bool CULL>
-__device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT_APEX_PLANES][RT_TILE],
-                                           ApexRay (&ray)[R], long j0, int wave, int lane,
-                                           unsigned long long& tiles_done, unsigned& kept)
+// Can any ray of the box lie in the triangle's bounding square sq = (cu, cv, rho, -)?  Interval
+// overlap in u and in v; the box is the exact hull of the rays' fp32 (u, v) and the few
+// roundings here are covered by the 1e-6 (the square's own allowance covers the per-ray test).
+__device__ __forceinline__ bool box_meets_square(const float4& sq, const WaveBox& b)
+{
+    const float reach_u = b.u_h + sq.z + 1e-6f, reach_v = b.v_h + sq.z + 1e-6f;
+    return __builtin_fabsf(b.u_c - sq.x) <= reach_u && __builtin_fabsf(b.v_c - sq.y) <= reach_v;
+}
+
+// Stages the planes of tile t of a light for rays of dominant axis AX: the four apex planes and
+// the bounding squares of that axis (plane RT_APEX_PLANES + AX of the light's set) as plane 4.
+template <int AX>
+__device__ __forceinline__ void stage_light_tile(const float4* __restrict__ planes, long plane_stride, int t,
+                                                 float4 (*buf)[RT_TILE], int wave, int lane)
+{
+    constexpr int NP = RT_APEX_PLANES + 1;
+#pragma unroll
+    for (int c = 0; c < (NP * (RT_TILE / 64) + 3) / 4; ++c) {
+        const int chunk = c * 4 + wave;                 // chunk = plane * (RT_TILE/64) + part
+        if (chunk < NP * (RT_TILE / 64)) {
+            const int plane = chunk / (RT_TILE / 64), part = chunk % (RT_TILE / 64);
+            const int src = plane < RT_APEX_PLANES ? plane : RT_APEX_PLANES + AX;
+            const long g = (long)src * plane_stride + (long)t * RT_TILE + part * 64 + lane;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(planes + g),
+                (__attribute__((address_space(3))) void*)&buf[plane][part * 64], 16, 0, 0);
+        }
+    }
+}
+
+// Stages the bounding squares of `count` (<= RT_CULL_GROUP) consecutive tiles from tile t on.
+template <int AX>
+__device__ __forceinline__ void stage_squares(const float4* __restrict__ planes, long plane_stride, int t,
+                                              int count, float4* buf, int wave, int lane)
+{
+    const float4* src = planes + (long)(RT_APEX_PLANES + AX) * plane_stride + (long)t * RT_TILE;
+#pragma unroll
+    for (int c = 0; c < (RT_CULL_GROUP * (RT_TILE / 64) + 3) / 4; ++c) {
+        const int part = c * 4 + wave;
+        if (part < count * (RT_TILE / 64))
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + part * 64 + lane),
+                (__attribute__((address_space(3))) void*)&buf[part * 64], 16, 0, 0);
+    }
+}
+
+// One triangle against the lane's R rays.  First test: is the ray's direction (u, v) inside the
+// triangle's bounding square on the plane of the dominant axis (k_pack_apex),
+//     max(|u - cu|, |v - cv|) <= rho
+// -- two subtractions and a maximum per pair, a three-way minimum per two pairs and one
+// comparison per triangle: 29 VALU instructions per 8 pairs.  A lane with a ray inside goes on
+// to the full inside test with its allowances (finish_apex), from the triangle's four apex
+// planes P, Q, Hh, N, which `planes` fetches (from the LDS tile, or from memory).
+template <int AX, int R, class Planes>
+__device__ __forceinline__ void apex_triangle(const SweepArgs& A, ApexRay (&ray)[R], long j0, const float4& sq,
+                                              int tri, Planes&& planes)
 {
     const float qnan = __builtin_nanf("");
-    WaveBox box{};
-    if constexpr (CULL) box = wave_box<R>(ray);
+    float m[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        m[r] = __builtin_fmaxf(__builtin_fabsf(ray[r].u - sq.x), __builtin_fabsf(ray[r].v - sq.y));
+    float mn = m[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) mn = __builtin_fminf(mn, m[r]);     // a retired ray's NaN is passed over
+    if (__builtin_expect(mn <= sq.z, 0)) {
+        Tri2 cur;
+        float4 Hh, N;
+        planes(cur, Hh, N);
+        unsigned pass = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) pass |= (m[r] <= sq.z ? 1u : 0u) << r;
+        while (pass) {
+            const int rs = __builtin_ctz(pass);
+            pass &= pass - 1;
+            float u = ray[0].u, v = ray[0].v;
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                u = rs == r ? ray[r].u : u;
+                v = rs == r ? ray[r].v : v;
+            }
+            if (finish_apex<AX>(A, u, v, j0 + (long)rs * 64, tri, cur, Hh, N)) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) ray[r].u = rs == r ? qnan : ray[r].u;
+            }
+        }
+    }
+}
+
+// After a tile: retire the workgroup once every ray in it is certainly occluded or unused; with
+// several chunks per ray the flag another chunk's workgroup may have set is polled every few
+// tiles (two dependent loads per ray: not free).  Returns true when the workgroup is done.
+template <int R>
+__device__ __forceinline__ bool apex_all_retired(const SweepArgs& A, ApexRay (&ray)[R], long j0, bool poll)
+{
+    const float qnan = __builtin_nanf("");
+    bool done = true;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (poll && ray[r].u == ray[r].u &&
+            (__hip_atomic_load(&A.cnt[A.active[j0 + r * 64]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
+             RT_CNT_OCCLUDED))
+            ray[r].u = qnan;
+        done = done && !(ray[r].u == ray[r].u);
+    }
+    return __syncthreads_and(done);
+}
+
+// The tile loop of one workgroup for rays of dominant axis AX, every pair tested.  A ray is
+// retired when its u is NaN: its distance from any square is NaN too and never passes.
+//
+// Shadow rays that survive a few ranges are scattered over the image, so what is rare is that
+// one lane has more than one ray inside a triangle's square.  The passes are therefore handled
+// lane-wise: every lane picks its first passing ray (a chain of selects), the wave finishes
+// those together, and the loop repeats only while some lane has another one.
+template <int AX, int R>
+__device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT_APEX_PLANES + 1][RT_TILE],
+                                           ApexRay (&ray)[R], long j0, int wave, int lane,
+                                           unsigned long long& tiles_done)
+{
     // this workgroup's share of the triangle range: chunk blockIdx.z of gridDim.z
     const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
     const int t_begin = t_first + (int)((long)t_count * blockIdx.z / gridDim.z);
     const int t_end = t_first + (int)((long)t_count * (blockIdx.z + 1) / gridDim.z);
     if (t_begin < t_end) {
-        stage_tile<RT_APEX_PLANES>(A.planes, A.plane_stride, t_begin, tile[0], wave, lane);
+        stage_light_tile<AX>(A.planes, A.plane_stride, t_begin, tile[0], wave, lane);
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
     }
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end)
-            stage_tile<RT_APEX_PLANES>(A.planes, A.plane_stride, t + 1, tile[buf ^ 1], wave, lane);
+        if (t + 1 < t_end) stage_light_tile<AX>(A.planes, A.plane_stride, t + 1, tile[buf ^ 1], wave, lane);
         const float4* __restrict__ base = tile[buf][0];
+        const float4* __restrict__ squares = tile[buf][RT_APEX_PLANES];
         const int tri0 = t * RT_TILE;
-        // one triangle (entry j of the tile) against the lane's R rays
-        auto apex_triangle = [&](const Tri2& cur, int j) {
-            // U * W' >= -c, with the product as a plain multiplication (a two-operand
-            // instruction: cheaper to issue and on power than the FMA with c; its one rounding
-            // is far inside the 0.1 % by which c exceeds the bound it stands for)
-            float s[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float U = dot_ax<AX>(ray[r].u, ray[r].v, cur.P);
-                const float Wp = dot_ax<AX>(ray[r].u, ray[r].v, cur.Q);
-                s[r] = U * Wp;
-            }
-            float mx = s[0];
-#pragma unroll
-            for (int r = 1; r < R; ++r) mx = __builtin_fmaxf(mx, s[r]);
-            const float nc = -cur.P.w;
-            if (__builtin_expect(mx >= nc, 0)) {
-                const float4 Hh = base[j + 2 * RT_TILE], N = base[j + 3 * RT_TILE];
-                unsigned pass = 0;
-#pragma unroll
-                for (int r = 0; r < R; ++r) pass |= (s[r] >= nc ? 1u : 0u) << r;
-                while (pass) {
-                    const int rs = __builtin_ctz(pass);
-                    pass &= pass - 1;
-                    float u = ray[0].u, v = ray[0].v;
-#pragma unroll
-                    for (int r = 1; r < R; ++r) {
-                        u = rs == r ? ray[r].u : u;
-                        v = rs == r ? ray[r].v : v;
-                    }
-                    if (finish_apex<AX>(A, u, v, j0 + (long)rs * 64, tri0 + j, cur, Hh, N)) {
-#pragma unroll
-                        for (int r = 0; r < R; ++r) ray[r].u = rs == r ? qnan : ray[r].u;
-                    }
-                }
-            }
-        };
-        if constexpr (CULL) {
-            // every lane tests one triangle of the tile against the wave's whole bundle; only
-            // the survivors meet the rays one by one
-            static_assert(RT_TILE % 64 == 0, "one triangle per lane and round");
-            if (((t - t_begin) & 15) == 15) box = wave_box<R>(ray);     // the bundle shrinks as rays retire
-#pragma unroll
-            for (int h = 0; h < RT_TILE / 64; ++h) {
-                const float4* mine = base + h * 64 + lane;
-                unsigned long long keep = __ballot(box_may_hit<AX>(mine[0], mine[RT_TILE], mine[2 * RT_TILE], box));
-                kept += __popcll(keep);
-                while (keep) {
-                    const int j = h * 64 + __builtin_ctzll(keep);
-                    keep &= keep - 1;
-                    apex_triangle(load_tri2(base + j), j);
-                }
-            }
-        } else {
-            Tri2 next = load_tri2(base);
+        // LDS reads are issued one triangle ahead by hand
+        float4 next = squares[0];
 #pragma unroll kApexUnroll
-            for (int j = 0; j < RT_TILE; ++j) {
-                const Tri2 cur = next;
-                next = load_tri2(base + ((j + 1) & (RT_TILE - 1)));
-                apex_triangle(cur, j);
-            }
+        for (int j = 0; j < RT_TILE; ++j) {
+            const float4 sq = next;
+            next = squares[(j + 1) & (RT_TILE - 1)];
+            apex_triangle<AX, R>(A, ray, j0, sq, tri0 + j, [&](Tri2& cur, float4& Hh, float4& N) {
+                cur = load_tri2(base + j);
+                Hh = base[j + 2 * RT_TILE];
+                N = base[j + 3 * RT_TILE];
+            });
         }
         ++tiles_done;
         __builtin_amdgcn_s_waitcnt(0);
-        // retire the workgroup once every ray in it is certainly occluded or unused; with
-        // several chunks per ray the flag another chunk's workgroup may have set is polled
-        // every few tiles (two dependent loads per ray: not free)
-        bool done = true;
         const bool poll = gridDim.z > 1 && ((t - t_begin) & (RT_APEX_POLL - 1)) == RT_APEX_POLL - 1;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (poll && ray[r].u == ray[r].u &&
-                (__hip_atomic_load(&A.cnt[A.active[j0 + r * 64]], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT) & RT_CNT_OCCLUDED))
-                ray[r].u = qnan;
-            done = done && !(ray[r].u == ray[r].u);
+        if (apex_all_retired<R>(A, ray, j0, poll)) break;
+    }
+}
+
+// The same with tile culling: only the bounding squares travel through LDS, RT_CULL_GROUP tiles
+// at a time.  Every lane first tests one triangle's square against the bounding box of the
+// wave's whole bundle of rays (box_meets_square); the survivors meet the rays one by one, and a
+// lane with a ray inside the square fetches the triangle's planes from memory.
+template <int AX, int R>
+__device__ __forceinline__ void apex_tiles_culled(const SweepArgs& A, float4 (*tile)[RT_CULL_GROUP * RT_TILE],
+                                                  ApexRay (&ray)[R], long j0, int wave, int lane,
+                                                  unsigned& kept)
+{
+    WaveBox box = wave_box<R>(ray);
+    const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
+    const int t_begin = t_first + (int)((long)t_count * blockIdx.z / gridDim.z);
+    const int t_end = t_first + (int)((long)t_count * (blockIdx.z + 1) / gridDim.z);
+    auto group = [&](int t) { return t_end - t < RT_CULL_GROUP ? t_end - t : RT_CULL_GROUP; };
+    if (t_begin < t_end) {
+        stage_squares<AX>(A.planes, A.plane_stride, t_begin, group(t_begin), tile[0], wave, lane);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    }
+    int round = 0;
+    for (int t = t_begin; t < t_end; t += RT_CULL_GROUP, ++round) {
+        const int buf = round & 1, count = group(t);
+        if (t + RT_CULL_GROUP < t_end)
+            stage_squares<AX>(A.planes, A.plane_stride, t + RT_CULL_GROUP, group(t + RT_CULL_GROUP), tile[buf ^ 1],
+                              wave, lane);
+        const float4* __restrict__ squares = tile[buf];
+        if ((round & 3) == 3) box = wave_box<R>(ray);      // the bundle shrinks as rays retire
+        for (int h = 0; h < count * (RT_TILE / 64); ++h) {
+            unsigned long long keep = __ballot(box_meets_square(squares[h * 64 + lane], box));
+            kept += __popcll(keep);
+            while (keep) {
+                const int j = h * 64 + __builtin_ctzll(keep);
+                keep &= keep - 1;
+                const long tri = (long)t * RT_TILE + j;
+                apex_triangle<AX, R>(A, ray, j0, squares[j], (int)tri, [&](Tri2& cur, float4& Hh, float4& N) {
+                    const float4* __restrict__ g = A.planes + tri;
+                    cur.P = g[0];
+                    cur.Q = g[A.plane_stride];
+                    Hh = g[2 * A.plane_stride];
+                    N = g[3 * A.plane_stride];
+                });
+            }
         }
-        if (__syncthreads_and(done)) break;
+        __builtin_amdgcn_s_waitcnt(0);
+        const bool poll = gridDim.z > 1 && (round & 3) == 3;
+        if (apex_all_retired<R>(A, ray, j0, poll)) break;
     }
 }
 
@@ -659,7 +725,9 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
 template <int R, bool CULL>
 __global__ void __launch_bounds__(RT_WG, R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
 {
-    __shared__ float4 tile[2][RT_APEX_PLANES][RT_TILE];
+    // all pairs: two buffers of one tile's five planes; tile culling: two of a group's squares
+    constexpr int kTileFloat4 = CULL ? RT_CULL_GROUP * RT_TILE : (RT_APEX_PLANES + 1) * RT_TILE;
+    __shared__ float4 lds[2][kTileFloat4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -680,9 +748,9 @@ __global__ void __launch_bounds__(RT_WG, R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES)
 
     ApexRay ray[R];
     const float qnan = __builtin_nanf("");
-    // a wave owns 64 R consecutive rays of the list (neighbours on the screen: the fewer
-    // triangles have any of them in their slab, the fewer rare-path entries the wave pays for);
-    // ray r of this lane: active[j0 + r * 64]
+    // a wave owns 64 R consecutive rays of the list (neighbours on the screen, or in direction
+    // once sorted: the fewer triangles have any of them in their square, the fewer rare-path
+    // entries the wave pays for); ray r of this lane: active[j0 + r * 64]
     const long j0 = (long)blockIdx.x * (RT_WG * R) + wave * (64 * R) + lane;
 
 #pragma unroll
@@ -704,7 +772,7 @@ __global__ void __launch_bounds__(RT_WG, R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES)
         }
         const double du = (axis == 0 ? D[1] : D[0]), dv = (axis == 2 ? D[1] : D[2]);
         const double dk = axis == 0 ? D[0] : (axis == 1 ? D[1] : D[2]);
-        // a retired ray carries a NaN direction: s is NaN and never passes the slab test
+        // a retired ray carries a NaN direction, which never passes a test
         ray[r].u = valid ? (float)(du / dk) : qnan;
         ray[r].v = valid ? (float)(dv / dk) : qnan;
         // one ray at a time: interleaving the fp64 set-up of all rays would make this prologue,
@@ -712,19 +780,25 @@ __global__ void __launch_bounds__(RT_WG, R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES)
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    unsigned long long tiles_done = 0;
-    unsigned kept = 0;      // tile culling: triangles that met this wave's rays one by one
-    switch (axis) {         // uniform over the workgroup
-    case 0: apex_tiles<0, R, CULL>(A, tile, ray, j0, wave, lane, tiles_done, kept); break;
-    case 1: apex_tiles<1, R, CULL>(A, tile, ray, j0, wave, lane, tiles_done, kept); break;
-    default: apex_tiles<2, R, CULL>(A, tile, ray, j0, wave, lane, tiles_done, kept); break;
-    }
-
-    // pairs tested one by one: all of them, or with tile culling those of each wave's survivors
-    if (CULL) {
+    if constexpr (CULL) {
+        unsigned kept = 0;      // triangles that met this wave's rays one by one
+        auto tile = reinterpret_cast<float4 (*)[RT_CULL_GROUP * RT_TILE]>(lds);
+        switch (axis) {         // uniform over the workgroup
+        case 0: apex_tiles_culled<0, R>(A, tile, ray, j0, wave, lane, kept); break;
+        case 1: apex_tiles_culled<1, R>(A, tile, ray, j0, wave, lane, kept); break;
+        default: apex_tiles_culled<2, R>(A, tile, ray, j0, wave, lane, kept); break;
+        }
+        // pairs tested one by one: those of each wave's survivors
         if (A.tests && lane == 0) atomicAdd(A.tests, (unsigned long long)kept * (64 * R));
-    } else if (A.tests && tid == 0) {
-        atomicAdd(A.tests, tiles_done * (unsigned long long)RT_TILE * (RT_WG * R));
+    } else {
+        unsigned long long tiles_done = 0;
+        auto tile = reinterpret_cast<float4 (*)[RT_APEX_PLANES + 1][RT_TILE]>(lds);
+        switch (axis) {
+        case 0: apex_tiles<0, R>(A, tile, ray, j0, wave, lane, tiles_done); break;
+        case 1: apex_tiles<1, R>(A, tile, ray, j0, wave, lane, tiles_done); break;
+        default: apex_tiles<2, R>(A, tile, ray, j0, wave, lane, tiles_done); break;
+        }
+        if (A.tests && tid == 0) atomicAdd(A.tests, tiles_done * (unsigned long long)RT_TILE * (RT_WG * R));
     }
 }
 

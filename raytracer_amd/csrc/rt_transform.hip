@@ -117,7 +117,7 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
             const int* __restrict__ iA, const int* __restrict__ iB, const int* __restrict__ iC,
             int num_tris, int num_tris_padded, const unsigned* __restrict__ max_bits,
             double px, double py, double pz, double zs, double dmax, int sign_layout,
-            const int32_t* __restrict__ order, float4* __restrict__ planes)
+            const int32_t* __restrict__ order, float4* __restrict__ planes, float4* __restrict__ squares)
 {
     const int i = blockIdx.x * RT_WG + threadIdx.x;      // entry of the plane arrays
     if (i >= num_tris_padded) return;
@@ -175,6 +175,10 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
     if (null_tri) {     // never passes: c = -1 in the product layout, positive constants in the sign layout
 #pragma unroll
         for (int k = 0; k < RT_APEX_PLANES; ++k) *p[k] = sign_layout ? make_float4(0, 0, 1.0f, 0) : null_entry;
+        if (squares) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) squares[(long)ax * num_tris_padded + i] = make_float4(0, 0, -1.0f, 0);
+        }
         return;
     }
     // p = a0 x e2, q = e2 x a1, h = e1 x a0, k = a0.nn -- formed in fp64, rounded once
@@ -229,12 +233,74 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
     *p[1] = make_float4((float)qx_, (float)qy_, (float)(zs * qz_), (float)m);
     *p[2] = make_float4((float)hx, (float)hy, (float)(zs * hz), (float)k);
     *p[3] = make_float4((float)nx, (float)ny, (float)(zs * nz), (float)en * 1.0000002f);
+    if (!squares) return;
+    // Bounding squares for the any-hit sweep's first test, one per dominant axis.  A ray of axis
+    // kk has the direction D' = (u, v) on the plane D_kk = 1 through P, |u|, |v| <= 1, and can
+    // only hit the triangle if (u, v) lies in the triangle's central projection onto that plane.
+    // Stored: (cu, cv, rho, 0) = the bounding square of that projection, clipped to the rays'
+    // square and grown by more than the fp32 rounding of the test and than the reference's own
+    // fp64 rounding can move a hit; rho = -1: no ray of this axis can hit (the triangle lies
+    // beyond one face of the double pyramid |D_u|, |D_v| <= |D_kk|); rho = +inf: no bound -- the
+    // triangle crosses or touches the plane D_kk = 0 inside the pyramid, or it is one of those
+    // for which the fp32 filter has no verdict (nearly degenerate, or P within rounding of its
+    // plane: the reference's rounding then decides hits anywhere along a line).
+    const bool no_verdict = !(m < 1e300) || !(fabs(k) > 9.3132257461547852e-10 * rho * l1 * l2);     // 2^-30
+    const double A0[3] = {a0x, a0y, a0z}, A1[3] = {a1x, a1y, a1z}, A2[3] = {a2x, a2y, a2z};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const int iu = ax == 0 ? 1 : 0, iv = ax == 2 ? 1 : 2;       // the (u, v) components of dot_ax
+        const double wk[3] = {A0[ax], A1[ax], A2[ax]}, wu[3] = {A0[iu], A1[iu], A2[iu]}, wv[3] = {A0[iv], A1[iv], A2[iv]};
+        float4 sq = make_float4(0, 0, __builtin_huge_valf(), 0);
+        const double grow = 1.000001;
+        bool beyond = false;        // all three vertices beyond the same face of the double pyramid
+        {
+            bool up = true, un = true, vp = true, vn = true;
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const double lim = fabs(wk[n]) * grow + 1e-9 * rho;
+                up = up && wu[n] > lim;
+                un = un && -wu[n] > lim;
+                vp = vp && wv[n] > lim;
+                vn = vn && -wv[n] > lim;
+            }
+            beyond = up || un || vp || vn;
+        }
+        const bool one_side = (wk[0] > 0 && wk[1] > 0 && wk[2] > 0) || (wk[0] < 0 && wk[1] < 0 && wk[2] < 0);
+        const double nearest = fmin(fabs(wk[0]), fmin(fabs(wk[1]), fabs(wk[2])));
+        if (beyond && !no_verdict) {
+            sq.z = -1.0f;
+        } else if (!no_verdict && one_side && nearest > 1e-6 * rho) {
+            double u0 = 1e300, u1 = -1e300, v0 = 1e300, v1 = -1e300;
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const double pu = wu[n] / wk[n], pv = wv[n] / wk[n];
+                u0 = fmin(u0, pu); u1 = fmax(u1, pu);
+                v0 = fmin(v0, pv); v1 = fmax(v1, pv);
+            }
+            // only |u|, |v| <= 1 matter
+            const double lim = 1.0 + 1e-6;
+            u0 = fmax(u0, -lim); u1 = fmin(u1, lim);
+            v0 = fmax(v0, -lim); v1 = fmin(v1, lim);
+            if (u0 > u1 || v0 > v1) {
+                sq.z = -1.0f;
+            } else if (u0 == u0 && u1 == u1 && v0 == v0 && v1 == v1) {
+                const double cu = 0.5 * (u0 + u1), cv = 0.5 * (v0 + v1);
+                const double half = fmax(0.5 * (u1 - u0), 0.5 * (v1 - v0));
+                // the centre is rounded to fp32 (<= 2^-24), the ray's u, v were (<= 2^-24 each), the
+                // two subtractions round (<= 2^-23 each): 1e-6 covers them; 1e-4 of the extent
+                // covers the reference's own rounding for every triangle that has a verdict
+                const float r = (float)(half * 1.0001 + 1e-6) * 1.0000002f;
+                sq = make_float4((float)cu, (float)cv, r, 0);
+            }
+        }
+        squares[(long)ax * num_tris_padded + i] = sq;
+    }
 }
 
 }  // namespace
 
 int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dmax, float4* dst,
-                        bool sign_layout, const int32_t* order, hipStream_t st)
+                        bool sign_layout, const int32_t* order, hipStream_t st, float4* squares)
 {
     const int np = sc->num_tris_padded;
     if (!dst) {
@@ -245,7 +311,7 @@ int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dm
                        sc->ex.as<double>(), sc->ey.as<double>(), sc->ez.as<double>(),
                        sc->iA.as<int>(), sc->iB.as<int>(), sc->iC.as<int>(), sc->num_tris, np,
                        sc->scratch_max.as<unsigned>(), apex[0], apex[1], apex[2], zs, dmax,
-                       sign_layout ? 1 : 0, order, dst);
+                       sign_layout ? 1 : 0, order, dst, squares);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("apex pack launch failed: %s", hipGetErrorString(e));

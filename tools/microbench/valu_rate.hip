@@ -73,6 +73,11 @@ KERNEL1(k_raster64, "v_fma_f32 %0, %8, %9, %0\n" "v_fma_f32 %1, %8, %9, %1\n" "v
 KERNEL1(k_apex8, "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %5, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %6, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %7, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %5, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %6, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %7, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %5, %2, %3, %0\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_fma_f32 %6, %2, %3, %0\n" "v_max_f32 %4, %5, %6\n" "v_max3_f32 %4, %4, %7, %5\n" "v_max3_f32 %4, %4, %6, %7\n" "v_max3_f32 %4, %4, %5, %6\n" "v_cmp_le_f32 vcc, 0, %4\n" )
 // the any-hit loop if it used the sign tests of the pixel-grid sweep (not adopted: shadow rays have no fixed sign of the determinant)
 KERNEL1(k_apex8_sign, "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_fma_f32 %2, %8, %9, %0\n" "v_fma_f32 %3, %8, %9, %1\n" "v_fmac_f32 %2, %9, %8\n" "v_fmac_f32 %3, %9, %8\n" "v_and_or_b32 %4, %2, %3, %4\n" "v_cmp_gt_i32 vcc, 0, %4\n" )
+// candidate first tests of the any-hit sweep on the projection plane of the dominant axis: the
+// bounding square (max(|du|, |dv|) <= rho) and the bounding circle (du^2 + dv^2 <= rho^2) of the
+// projected triangle, 8 rays per lane
+KERNEL1(k_apex8_box, "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_max_f32_e64 %5, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_max_f32_e64 %6, |%2|, |%3|\n" "v_min3_f32 %4, %4, %5, %6\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_max_f32_e64 %5, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_max_f32_e64 %6, |%2|, |%3|\n" "v_min3_f32 %4, %4, %5, %6\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_max_f32_e64 %5, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_max_f32_e64 %6, |%2|, |%3|\n" "v_min3_f32 %4, %4, %5, %6\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_max_f32_e64 %5, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_max_f32_e64 %6, |%2|, |%3|\n" "v_min3_f32 %4, %4, %5, %6\n" "v_cmp_ge_f32 vcc, %7, %4\n" )
+KERNEL1(k_apex8_circle, "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_mul_f32 %5, %2, %2\n" "v_fmac_f32 %5, %3, %3\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_mul_f32 %6, %2, %2\n" "v_fmac_f32 %6, %3, %3\n" "v_min3_f32 %4, %4, %5, %6\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_mul_f32 %5, %2, %2\n" "v_fmac_f32 %5, %3, %3\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_mul_f32 %6, %2, %2\n" "v_fmac_f32 %6, %3, %3\n" "v_min3_f32 %4, %4, %5, %6\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_mul_f32 %5, %2, %2\n" "v_fmac_f32 %5, %3, %3\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_mul_f32 %6, %2, %2\n" "v_fmac_f32 %6, %3, %3\n" "v_min3_f32 %4, %4, %5, %6\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_mul_f32 %5, %2, %2\n" "v_fmac_f32 %5, %3, %3\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_mul_f32 %6, %2, %2\n" "v_fmac_f32 %6, %3, %3\n" "v_min3_f32 %4, %4, %5, %6\n" "v_cmp_ge_f32 vcc, %7, %4\n" )
 template <class K>
 void run_mix(const char* name, K k, float* out, int wgs, int instrs, int pairs)
 {
@@ -145,6 +150,8 @@ int main()
     run_mix("raster64", k_raster64, out, wgs, 195, 64);
     run_mix("apex8", k_apex8, out, wgs, 45, 8);
     run_mix("apex8_sign", k_apex8_sign, out, wgs, 41, 8);
+    run_mix("apex8_box", k_apex8_box, out, wgs, 29, 8);
+    run_mix("apex8_circle", k_apex8_circle, out, wgs, 37, 8);
     (void)hipFree(out);
     return 0;
 }
