@@ -395,7 +395,7 @@ def main() -> None:
                                "frac": tests_per_s_launch * instr_per_test / 1e12 / PEAK_VALU_TINSTR,
                                # the same instruction sequence with nothing around it (no LDS reads,
                                # barriers, branches or rare path), measured by tools/microbench/valu_rate
-                               **mix_alone(f"raster{mix_ppl}", tests_per_s_launch)},
+                               **mix_alone(f"raster{mix_ppl}_box", tests_per_s_launch)},
                 "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
                 "sweep_kernel": {"tile_tris": tile.value, "pixels_per_lane": ppl.value,

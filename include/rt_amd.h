@@ -270,10 +270,11 @@ int rt_apex_sweep_config(int* tile_tris, int* primary_pixels_per_lane,
                          double* primary_flop_per_pair, int* shadow_rays_per_lane,
                          double* shadow_flop_per_pair, int* primary_chunks);
 /* VALU instructions of the pixel-grid sweep's hot loop per lane and triangle, i.e. per
- * *pixels_per_lane pixel-triangle pairs (of the most recent primary sweep): fp32 FMAs, fp32
- * additions, 32-bit logic instructions and compares.  The loop is bound by instruction issue,
- * not by flops: most of its arithmetic is additions that step a plane distance from one pixel
- * of the lane to the next. */
+ * *pixels_per_lane pixel-triangle pairs (of the most recent primary sweep): fp32 FMAs (none),
+ * fp32 additions / subtractions, three-way minima (reported as `logic`) and compares.  The loop
+ * is bound by instruction issue, not by flops: its arithmetic is additions that step the
+ * distance from the centre of a triangle's bounding box from one pixel of the lane to the
+ * next, and minima that collect them. */
 int rt_raster_sweep_mix(int* pixels_per_lane, int* fma, int* add, int* logic, int* compare);
 /* Tile culling (off by default): before a tile of 128 triangles meets a wave's rays one by one,
  * every triangle of the tile is tested once against the wave's whole bundle -- the pixel

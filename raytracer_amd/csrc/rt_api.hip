@@ -332,7 +332,7 @@ extern "C" int rt_scene_set_triangles(rt_scene* sc, int num_tris, const int* A, 
     if (sc->num_tris_padded == 0) sc->num_tris_padded = RT_TILE;
     const size_t pb = sizeof(float4) * (size_t)sc->num_tris_padded;
     RT_TRY(sc->planes.reserve(pb * RT_PLANES));
-    RT_TRY(sc->planes_apex.reserve(pb * RT_APEX_PLANES));
+    RT_TRY(sc->planes_apex.reserve(pb * (RT_APEX_PLANES + 1)));     // + the pixel-grid bounding boxes
     RT_TRY(sc->tri_verts.reserve(sizeof(double) * 9 * (size_t)(num_tris > 0 ? num_tris : 1)));
     RT_TRY(sc->scratch_max.reserve(16));
     sc->transformed = false;
@@ -669,7 +669,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     const double eye[3] = {0, 0, 0};                    // driver.c:121-123
     const double hw = 0.5 * W + 1, hh = 0.5 * H + 1;
     RT_TRY(rt_launch_pack_apex(sc, eye, ez, sqrt(hw * hw + hh * hh + ez * ez), sc->planes_apex.as<float4>(), true,
-                               nullptr, st));
+                               nullptr, st, sc->planes_apex.as<float4>() + (size_t)RT_APEX_PLANES * sc->num_tris_padded));
 
     SweepArgs a{};
     a.planes = sc->planes_apex.as<float4>(); a.plane_stride = sc->num_tris_padded;

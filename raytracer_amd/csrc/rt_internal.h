@@ -77,15 +77,16 @@ constexpr int RT_APEX_PLANES = 4;
 constexpr int RT_LIGHT_PLANES = RT_APEX_PLANES + 3;
 constexpr int RT_APEX_LIGHTS = 4;   // lights swept per any-hit launch (plane sets kept side by side)
 constexpr int RT_APEX_SETS = 3 * RT_APEX_LIGHTS;    // ray sets per launch: light x dominant axis
-// Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels): 2 FMA for the row terms,
-// 2 FMA for the first pixel of every 8, 2 additions for each further pixel, then per pixel one
-// logic instruction on the two sign bits, and one compare.  Any-hit apex sweep, per pair: two
+// Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels): the distances of the
+// first pixel and of the row from the box's centre (2 subtractions), one addition for each
+// further pixel, a three-way minimum per two pixels (`logic`) and two compares: 99 instructions
+// per 64 pairs, one flop per pair.  Any-hit apex sweep, per pair: two
 // subtractions and a maximum (the bounding-square test), a three-way minimum per two pairs and a
 // compare per eight: 29 instructions per 8 pairs, 2 flops per pair.
 struct RasterMix { int fma, add, logic, compare; };
 constexpr RasterMix rt_raster_mix(int rpl)
 {
-    return RasterMix{2 + 2 * ((rpl + 7) / 8), 2 * (rpl - (rpl + 7) / 8), rpl, 1};
+    return RasterMix{0, rpl + 1, rpl > 1 ? rpl / 2 : 0, 2};
 }
 // fp32 flops per pair (FMA = 2) of that loop
 constexpr double rt_raster_flop_per_pair(int rpl)

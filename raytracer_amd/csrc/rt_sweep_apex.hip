@@ -28,17 +28,21 @@
 //                   state through atomics, an occluder cache in front (host side:
 //                   trace_shadow_rays in rt_api.hip).
 //   k_sweep_raster  closest hit for the pixel grid.  D = (X, Y, ez) with integer X, Y and a
-//                   constant ez that k_pack_apex folds into the z components.  Primary rays
-//                   leave P, which fixes the sign of det for a hit, so k_pack_apex orients every
-//                   triangle and the slab is U >= 0 and W' >= 0: two sign bits.  Each lane owns
-//                   RT_RASTER_RPL pixels of one row, RT_RASTER_COLS columns apart; the row part
-//                   Y*p.y + ez*p.z is formed once per lane and triangle, the first pixel costs
-//                   two FMAs and every further one two additions, and one logic instruction per
-//                   pixel combines the sign bits: 195 VALU instructions per 64 pairs.  Every
-//                   (pixel, triangle) pair is still tested individually.
+//                   constant ez that k_pack_apex folds into the z components.  Each lane owns
+//                   RT_RASTER_RPL pixels of one row, RT_RASTER_COLS columns apart.  First test of
+//                   a pair: the pixel against the bounding box of the triangle's projection
+//                   onto the image plane (k_pack_apex writes one per triangle, allowances
+//                   included): the distance from the box's centre steps by one from pixel to
+//                   pixel of the lane -- one addition per pixel and a three-way minimum per two
+//                   pixels, 99 VALU instructions per 64 pairs.  Every (pixel, triangle) pair is
+//                   still tested individually.  Primary rays leave P, which fixes the sign of
+//                   det for a hit, so k_pack_apex orients every triangle (sign layout) for
+//                   the rare path's inside test.
 //
-// Tiles of RT_TILE triangles (4 planes) are double-buffered in LDS by LDS-DMA loads and read
-// at wave-uniform addresses (broadcast, no bank conflicts).
+// The sweeps stream what their first test reads through LDS in tiles of RT_TILE triangles,
+// double-buffered by LDS-DMA loads and read at wave-uniform addresses (broadcast, no bank
+// conflicts): the boxes for the pixel grid (the rare path fetches a triangle's planes from
+// memory), the squares and the four planes for the any-hit sweep.
 #include "rt_sweep_common.h"
 
 #ifndef RT_APEX8_WAVES
@@ -74,15 +78,6 @@ constexpr int kApexUnroll = RT_APEX_UNROLL;
 
 struct Tri2 { float4 P, Q; };
 
-// (a & b) | c on the bit patterns, as the one instruction it is.  Spelled out because the
-// optimiser otherwise rebalances the chain of these over a lane's pixels into separate ands and
-// a tree of three-input ors: 40 % more instructions and twice the registers.
-__device__ __forceinline__ int and_or(float a, float b, int c)
-{
-    int r;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
 __device__ __forceinline__ Tri2 load_tri2(const float4* p) { return {p[0], p[RT_TILE]}; }
 
 // ------------------------------------------------------------------------------------------
@@ -103,20 +98,28 @@ __device__ __forceinline__ void push_mem(const SweepArgs& A, long slot, int tri)
     if (c < RT_RASTER_LIST_K) A.list[slot * RT_RASTER_LIST_K + c] = tri;
 }
 
-// The rest of the inside test for one pixel that passed the sign tests of triangle `tri`
-// (candidate() of rt_sweep_common.h with the bookkeeping in memory).  Xs = the pixel's X / RT_RASTER_COLS,
-// un = its first sign-test value -(U + delta); p = the triangle's plane 0 in the LDS tile.
-__device__ __forceinline__ void finish_raster(const SweepArgs& A, long slot, int tri, const Tri2& q,
-                                              const float4* __restrict__ p, float Xs, float Y, float un)
+// min(a, |b|, |c|) as the one instruction it is (the optimiser otherwise turns the chain of these
+// over a lane's pixels into separate two-operand minima)
+__device__ __forceinline__ float min3_abs(float a, float b, float c)
 {
-    const float4 Hh = p[2 * RT_TILE], N = p[3 * RT_TILE];
-    const float margin = q.Q.w;
+    float r;
+    asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// The inside test for one pixel that lies in the bounding box of triangle `tri` (candidate() of
+// rt_sweep_common.h with the bookkeeping in memory).  Xs = the pixel's X / RT_RASTER_COLS;
+// P, Hh, N = the triangle's planes 0, 2, 3 (sign layout of k_pack_apex), margin = plane 1's w.
+__device__ __forceinline__ void finish_raster(const SweepArgs& A, long slot, int tri, const float4& P, float margin,
+                                              const float4& Hh, const float4& N, float Xs, float Y)
+{
     if (margin == INF) {            // no fp32 verdict for this triangle (see k_pack_apex)
         push_mem(A, slot, tri);
         return;
     }
     const float X = (float)RT_RASTER_COLS * Xs;
-    const float U = -un - q.P.w;
+    // plane 0 holds -(U + delta)
+    const float U = -__builtin_fmaf(Xs, P.x, __builtin_fmaf(Y, P.y, P.z)) - P.w;
     const float V = __builtin_fmaf(X, Hh.x, __builtin_fmaf(Y, Hh.y, Hh.z));
     const float d = __builtin_fmaf(X, N.x, __builtin_fmaf(Y, N.y, N.z));
     const float a = U * d, b = V * d;
@@ -143,61 +146,91 @@ __device__ __forceinline__ void finish_raster(const SweepArgs& A, long slot, int
         atomicMin(reinterpret_cast<int*>(A.best_hi + slot), __float_as_int(t + terr));
 }
 
-// The pixel rectangle of a wave, for the tile-culling variant: centre and half extents in the
-// units the planes are evaluated in (xs = X / RT_RASTER_COLS for planes 0 and 1, x = X for
-// planes 2 and 3).  All values are multiples of 1/16 below 2^13: exact in fp32.
-struct WaveRect { float xs_c, xs_h, x_c, x_h, y_c, y_h; };
-
-// Can any pixel of the rectangle pass the inside test of this triangle?  The four edge
-// functions are affine in (X, Y), so over the rectangle each is bounded by its centre value
-// and |dX| hx + |dY| hy.  A hit has un < 0, wn < 0 (plane 0, 1: -(U + delta), -(W' + delta)),
-// V >= 0 and det - U - V >= 0 for the orientation-normalised triangle; the rectangle is
-// dropped only when one of them fails everywhere by a clear multiple of the per-pixel test's
-// own allowances (delta for the slab, the margin m = 32 delta for the other two edges), which
-// is far more than the rounding of these few fp32 operations (a few 2^-24 of the same
-// magnitudes delta is 2^-20 of).  A NaN or infinite plane entry makes the comparisons false:
-// the triangle is kept and the per-pixel tests decide as they would without culling.
-__device__ __forceinline__ bool rect_may_hit(const float4& P, const float4& Q, const float4& Hh, const float4& N,
-                                             const WaveRect& w)
+// One triangle against the R pixels of a lane.  box = (cx, rx, cy, ry): the triangle's bounding
+// box on the pixel grid, x in units of RT_RASTER_COLS pixels (k_pack_apex).  First test of every
+// pair: |Xs - cx| <= rx, with Xs - cx stepping by one from pixel to pixel of the lane -- one
+// addition per pixel and one three-way minimum per two pixels; the row test |Y - cy| <= ry is
+// the lane's.  A lane with a pixel inside fetches the triangle's planes from memory (tri is
+// wave-uniform) and runs the inside test on the pixels of the box.
+template <int R>
+__device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4& box, int tri, float Xs0, float Y,
+                                                unsigned long long on_image, long slot0)
 {
-    const float grow = 1.000001f;
-    const float delta = P.w, margin = Q.w;
-    const float cu = __builtin_fmaf(w.xs_c, P.x, __builtin_fmaf(w.y_c, P.y, P.z));
-    const float ru = __builtin_fmaf(__builtin_fabsf(P.x), w.xs_h, __builtin_fabsf(P.y) * w.y_h) * grow;
-    if (cu - ru > delta) return false;
-    const float cw = __builtin_fmaf(w.xs_c, Q.x, __builtin_fmaf(w.y_c, Q.y, Q.z));
-    const float rw = __builtin_fmaf(__builtin_fabsf(Q.x), w.xs_h, __builtin_fabsf(Q.y) * w.y_h) * grow;
-    if (cw - rw > delta) return false;
-    const float cv = __builtin_fmaf(w.x_c, Hh.x, __builtin_fmaf(w.y_c, Hh.y, Hh.z));
-    const float rv = __builtin_fmaf(__builtin_fabsf(Hh.x), w.x_h, __builtin_fabsf(Hh.y) * w.y_h) * grow;
-    if (cv + rv < -2.0f * margin) return false;
-    // W3 = det - U - V with U = -un - delta: coefficients formed here
-    const float inv_cols = 1.0f / RT_RASTER_COLS;
-    const float gx = __builtin_fmaf(P.x, inv_cols, N.x) - Hh.x, gy = (N.y + P.y) - Hh.y;
-    const float gz = ((N.z + P.z) + delta) - Hh.z;
-    const float cg = __builtin_fmaf(w.x_c, gx, __builtin_fmaf(w.y_c, gy, gz));
-    const float rg = __builtin_fmaf(__builtin_fabsf(gx), w.x_h, __builtin_fabsf(gy) * w.y_h) * grow;
-    if (cg + rg < -2.0f * margin) return false;
-    return true;
+    constexpr int COLS = RT_RASTER_COLS;
+    const float d0 = Xs0 - box.x;
+    float acc = INF;
+    if (R == 1) acc = __builtin_fabsf(d0);
+#pragma unroll
+    for (int r = 0; r + 1 < R; r += 2) acc = min3_abs(acc, d0 + (float)r, d0 + (float)(r + 1));
+    if (__builtin_expect(acc <= box.y && __builtin_fabsf(Y - box.z) <= box.w, 0)) {
+        // the pixels of the box: r with |d0 + r| <= rx, one more on either side for the rounding
+        // of these two bounds (the inside test decides about every pixel it is given)
+        int r = (int)__builtin_floorf(__builtin_fmaxf(-box.y - d0, 0.0f)) - 1;
+        int r_hi = (int)__builtin_ceilf(__builtin_fminf(box.y - d0, (float)(R - 1))) + 1;
+        r = r < 0 ? 0 : r;
+        r_hi = r_hi > R - 1 ? R - 1 : r_hi;
+#if RT_RASTER_CHECK_INTERVAL
+        {
+            unsigned long long pass = 0;
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                pass |= (unsigned long long)(__builtin_fabsf(d0 + (float)k) <= box.y ? 1 : 0) << k;
+            const unsigned long long inside =
+                r > r_hi ? 0ull : ((r_hi >= 63 ? ~0ull : (2ull << r_hi) - 1ull) & ~((1ull << r) - 1ull));
+            if ((pass & ~inside) && A.tests) atomicAdd(A.tests, 1ull << 48);
+        }
+#endif
+        const float4* __restrict__ g = A.planes + tri;
+        const float4 P = g[0], Hh = g[2 * A.plane_stride], N = g[3 * A.plane_stride];
+        const float margin = g[A.plane_stride].w;
+        for (; r <= r_hi; ++r)
+            if ((on_image >> r) & 1ull) finish_raster(A, slot0 + COLS * r, tri, P, margin, Hh, N, Xs0 + (float)r, Y);
+    }
 }
 
-// CULL: every tile's triangles are first tested against the wave's whole pixel rectangle, one
-// triangle per lane (rect_may_hit), and only the survivors go through the per-pixel tests.
-// The candidates that reach the exact pass are still a superset of the true hits, so the
-// results are the same; what changes is that most (pixel, triangle) pairs are decided 4096 at a
-// time instead of one by one.
+// The pixel rectangle of a wave, for the tile-culling variant: centre and half extents, x in
+// units of RT_RASTER_COLS pixels like the boxes.  Exact in fp32.
+struct WaveRect { float xs_c, xs_h, y_c, y_h; };
+
+// Can any pixel of the rectangle lie in the triangle's box?  Interval overlap in x and y.
+__device__ __forceinline__ bool rect_meets_box(const float4& box, const WaveRect& w)
+{
+    return __builtin_fabsf(w.xs_c - box.x) <= w.xs_h + box.y && __builtin_fabsf(w.y_c - box.z) <= w.y_h + box.w;
+}
+
+// Stages the bounding boxes of `count` (<= RT_CULL_GROUP) consecutive tiles from tile t on.
+__device__ __forceinline__ void stage_boxes(const float4* __restrict__ boxes, int t, int count, float4* buf,
+                                            int wave, int lane)
+{
+    const float4* src = boxes + (long)t * RT_TILE;
+#pragma unroll
+    for (int c = 0; c < (RT_CULL_GROUP * (RT_TILE / 64) + 3) / 4; ++c) {
+        const int part = c * 4 + wave;
+        if (part < count * (RT_TILE / 64))
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + part * 64 + lane),
+                (__attribute__((address_space(3))) void*)&buf[part * 64], 16, 0, 0);
+    }
+}
+
+// Only the boxes travel through LDS, RT_CULL_GROUP tiles at a time, double-buffered by LDS-DMA
+// loads and read at wave-uniform addresses (broadcast, no bank conflicts).
+// CULL: every lane first tests ONE triangle's box against the wave's whole pixel rectangle, and
+// only the survivors meet the pixels one by one.  The candidates that reach the exact pass are
+// the same either way; what changes is that most (pixel, triangle) pairs are then decided 64 R
+// at a time instead of one by one.
 template <int R, bool CULL>
 __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const SweepArgs A)
 {
-    __shared__ float4 tile[2][RT_APEX_PLANES][RT_TILE];
+    __shared__ float4 tile[2][RT_CULL_GROUP * RT_TILE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
     // wave = (COLS R) x (64 / COLS) pixels; lane = one row, R pixels COLS apart; workgroup = its
-    // four waves side by side ((16 R) x 16 pixels), two by two or stacked.  (The squarer a wave's pixels, the fewer
-    // triangles have one of them in their slab: the rare path is paid per wave.)
+    // four waves side by side ((16 R) x 16 pixels), two by two or stacked.  (The squarer a wave's
+    // pixels, the fewer triangles have one of them in their box: the rare path is paid per wave.)
     constexpr int COLS = RT_RASTER_COLS;
     static_assert(64 / COLS == RT_TILE_H, "a wave covers RT_TILE_H rows");
     // the four waves: waves_x side by side, the rest below (whichever wastes fewer pixels beyond
@@ -225,8 +258,8 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
     // ray number: local pixel (the triangle chunks of a pixel share its count, list and bound)
     const long slot0 = (long)lr * A.W + px0;
 
-    // pixel r of the lane has X = px0 + COLS r - W/2 (driver.c:131); the planes carry COLS p.x,
-    // so the sweep works with X / COLS = Xs0 + r (exact in fp32)
+    // pixel r of the lane has X = px0 + COLS r - W/2 (driver.c:131); the planes and boxes are in
+    // units of COLS pixels, so the sweep works with X / COLS = Xs0 + r (exact in fp32)
     const float Xs0 = (float)(px0 - A.W / 2) * (1.0f / COLS);
     unsigned long long on_image = 0;        // bit r: pixel r of the lane exists
 #pragma unroll
@@ -245,130 +278,57 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
             ya = __builtin_fminf(ya, __shfl_xor(ya, off));
             yb = __builtin_fmaxf(yb, __shfl_xor(yb, off));
         }
-        rect.x_c = 0.5f * (xa + xb);
-        rect.x_h = 0.5f * (xb - xa);
-        rect.xs_c = rect.x_c * (1.0f / COLS);
-        rect.xs_h = rect.x_h * (1.0f / COLS);
+        rect.xs_c = 0.5f * (xa + xb) * (1.0f / COLS);
+        rect.xs_h = 0.5f * (xb - xa) * (1.0f / COLS);
         rect.y_c = 0.5f * (ya + yb);
         rect.y_h = 0.5f * (yb - ya);
     }
-
-    // One triangle against the R pixels of the lane: the sign tests of every pixel and, where one
-    // passes, the rest of the inside test.  cur = the triangle's planes 0 and 1, p = its plane 0
-    // in the LDS tile.
-    auto raster_triangle = [&](const Tri2& cur, const float4* __restrict__ p, int tri) {
-        // sign tests (k_pack_apex, sign layout): un = -(U + delta) and wn = -(W' + delta) of an
-        // orientation-normalised triangle are both negative exactly when the pixel is in the
-        // u slab, allowance included; their sign bits are and-ed per pixel and or-ed over
-        // the lane's pixels
-        const float yu = __builtin_fmaf(Y, cur.P.y, cur.P.z);
-        const float yw = __builtin_fmaf(Y, cur.Q.y, cur.Q.z);
-        float un = __builtin_fmaf(Xs0, cur.P.x, yu);
-        float wn = __builtin_fmaf(Xs0, cur.Q.x, yw);
-        int acc = __float_as_int(un) & __float_as_int(wn);
-#pragma unroll
-        for (int r = 1; r < R; ++r) {
-            if (r % 8 == 0) {       // a fresh start every 8 pixels bounds the rounding of the steps
-                un = __builtin_fmaf(Xs0 + (float)r, cur.P.x, yu);
-                wn = __builtin_fmaf(Xs0 + (float)r, cur.Q.x, yw);
-            } else {
-                un += cur.P.x;      // X / COLS grows by one from pixel to pixel
-                wn += cur.Q.x;
-            }
-            acc = and_or(un, wn, acc);
-        }
-        if (__builtin_expect(acc < 0, 0)) {
-            // Which pixels.  un and wn are linear along the lane's pixels, so the pixels where
-            // both are negative form one interval; its ends come from two divisions, and
-            // only the pixels inside it are evaluated again, each from its own X with the
-            // FMAs that decide (not kept in the hot loop).  The interval is a superset: a
-            // pixel whose FMA value is negative has a negative exact value, and the model
-            // u0 + r d differs from the exact value by the one rounding of u0.
-            const float u0 = __builtin_fmaf(Xs0, cur.P.x, yu), w0 = __builtin_fmaf(Xs0, cur.Q.x, yw);
-            float lo = 0.0f, hi = (float)(R - 1);
-            {
-                const float d = cur.P.x + 0.0f;         // -0 counts as +0
-                const float q = __builtin_fmaf(U22, __builtin_fabsf(u0), -u0) * __builtin_amdgcn_rcpf(d);
-                if (d < 0.0f) lo = __builtin_fmaxf(lo, q - 0.001f);      // r d < tol - u0  <=>  r > q
-                else hi = __builtin_fminf(hi, q + 0.001f);               //                 <=>  r < q
-            }
-            {
-                const float d = cur.Q.x + 0.0f;
-                const float q = __builtin_fmaf(U22, __builtin_fabsf(w0), -w0) * __builtin_amdgcn_rcpf(d);
-                if (d < 0.0f) lo = __builtin_fmaxf(lo, q - 0.001f);
-                else hi = __builtin_fminf(hi, q + 0.001f);
-            }
-            // (a NaN quotient leaves its bound alone: fmin / fmax return the other operand)
-            int r = (int)__builtin_ceilf(__builtin_fminf(lo, (float)R));
-            const int r_hi = (int)__builtin_floorf(__builtin_fmaxf(hi, -1.0f));
-#if RT_RASTER_CHECK_INTERVAL
-            {
-                unsigned long long pass = 0;
-#pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    const float Xs = Xs0 + (float)k;
-                    const float u1 = __builtin_fmaf(Xs, cur.P.x, yu);
-                    const float w1 = __builtin_fmaf(Xs, cur.Q.x, yw);
-                    pass |= (unsigned long long)((unsigned)(__float_as_int(u1) & __float_as_int(w1)) >> 31) << k;
-                }
-                const unsigned long long inside =
-                    r > r_hi ? 0ull : ((r_hi >= 63 ? ~0ull : (2ull << r_hi) - 1ull) & ~((1ull << r) - 1ull));
-                if ((pass & ~inside) && A.tests) atomicAdd(A.tests, 1ull << 48);
-            }
-#endif
-            for (; r <= r_hi; ++r) {
-                const float Xs = Xs0 + (float)r;
-                const float u1 = __builtin_fmaf(Xs, cur.P.x, yu);
-                const float w1 = __builtin_fmaf(Xs, cur.Q.x, yw);
-                if ((__float_as_int(u1) & __float_as_int(w1)) < 0 && ((on_image >> r) & 1ull))
-                    finish_raster(A, slot0 + COLS * r, tri, cur, p, Xs, Y, u1);
-            }
-        }
-    };
 
     // this workgroup's share of the triangle range: chunk blockIdx.y of gridDim.y
     const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
     const int t_begin = t_first + (int)((long)t_count * blockIdx.y / gridDim.y);
     const int t_end = t_first + (int)((long)t_count * (blockIdx.y + 1) / gridDim.y);
+    const float4* __restrict__ boxes = A.planes + (long)RT_APEX_PLANES * A.plane_stride;
+    auto group = [&](int t) { return t_end - t < RT_CULL_GROUP ? t_end - t : RT_CULL_GROUP; };
     unsigned long long tiles_done = 0;
     unsigned kept = 0;              // tile culling: triangles that went on to the per-pixel tests
     if (t_begin < t_end) {
-        stage_tile<RT_APEX_PLANES>(A.planes, A.plane_stride, t_begin, tile[0], wave, lane);
+        stage_boxes(boxes, t_begin, group(t_begin), tile[0], wave, lane);
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
     }
-    for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end)
-            stage_tile<RT_APEX_PLANES>(A.planes, A.plane_stride, t + 1, tile[buf ^ 1], wave, lane);
-        const float4* __restrict__ base = tile[buf][0];
+    int round = 0;
+    for (int t = t_begin; t < t_end; t += RT_CULL_GROUP, ++round) {
+        const int buf = round & 1, count = group(t);
+        if (t + RT_CULL_GROUP < t_end)
+            stage_boxes(boxes, t + RT_CULL_GROUP, group(t + RT_CULL_GROUP), tile[buf ^ 1], wave, lane);
+        const float4* __restrict__ base = tile[buf];
         const int tri0 = t * RT_TILE;
         if constexpr (CULL) {
-            static_assert(RT_TILE % 64 == 0, "one triangle per lane and round");
-#pragma unroll
-            for (int h = 0; wave_on && h < RT_TILE / 64; ++h) {
-                const float4* mine = base + h * 64 + lane;
-                unsigned long long keep =
-                    __ballot(rect_may_hit(mine[0], mine[RT_TILE], mine[2 * RT_TILE], mine[3 * RT_TILE], rect));
+            for (int h = 0; wave_on && h < count * (RT_TILE / 64); ++h) {
+                unsigned long long keep = __ballot(rect_meets_box(base[h * 64 + lane], rect));
                 kept += __popcll(keep);
                 while (keep) {
                     const int j = h * 64 + __builtin_ctzll(keep);
                     keep &= keep - 1;
-                    raster_triangle(load_tri2(base + j), base + j, tri0 + j);
+                    raster_triangle<R>(A, base[j], tri0 + j, Xs0, Y, on_image, slot0);
                 }
             }
         } else {
             // LDS reads are issued one triangle ahead by hand (the rare path splits the body into
             // basic blocks, which keeps the compiler from hoisting them)
-            Tri2 next = load_tri2(base);
+            for (int sub = 0; wave_on && sub < count; ++sub) {
+                const float4* __restrict__ b = base + sub * RT_TILE;
+                float4 next = b[0];
 #pragma unroll kRasterUnroll
-            for (int j = 0; wave_on && j < RT_TILE; ++j) {
-                const Tri2 cur = next;
-                next = load_tri2(base + ((j + 1) & (RT_TILE - 1)));     // last iteration re-reads entry 0 (unused)
-                raster_triangle(cur, base + j, tri0 + j);
+                for (int j = 0; j < RT_TILE; ++j) {
+                    const float4 box = next;
+                    next = b[(j + 1) & (RT_TILE - 1)];      // the last iteration re-reads entry 0 (unused)
+                    raster_triangle<R>(A, box, tri0 + sub * RT_TILE + j, Xs0, Y, on_image, slot0);
+                }
             }
         }
-        ++tiles_done;
+        tiles_done += count;
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
     }

@@ -175,7 +175,8 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
     if (null_tri) {     // never passes: c = -1 in the product layout, positive constants in the sign layout
 #pragma unroll
         for (int k = 0; k < RT_APEX_PLANES; ++k) *p[k] = sign_layout ? make_float4(0, 0, 1.0f, 0) : null_entry;
-        if (squares) {
+        if (squares && sign_layout) squares[i] = make_float4(0, -1.0f, 0, -1.0f);
+        if (squares && !sign_layout) {
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) squares[(long)ax * num_tris_padded + i] = make_float4(0, 0, -1.0f, 0);
         }
@@ -213,6 +214,40 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
         // plane, which includes the nearly degenerate triangles) no fp32 verdict is possible and
         // every pixel passes the triangle on to the exact pass.
         const bool ambiguous = !(fabs(k) > 9.3132257461547852e-10 * rho * l1 * l2);     // 2^-30
+        if (squares) {
+            // Bounding box of the triangle on the pixel grid, the sweep's first test of a pair: a
+            // pixel (X, Y) can only see the triangle if it lies in the triangle's central
+            // projection onto the image plane z = zs.  Stored: (cx / c, rx / c, cy, ry) with
+            // c = RT_RASTER_COLS (the sweep works with X / c), grown by more than the fp32
+            // rounding of the test (the centre and two subtractions, at magnitudes up to dmax)
+            // and than the reference's own fp64 rounding can move a hit; r = -1: behind the eye;
+            // r = +inf: no bound -- the triangle reaches the eye's plane z = 0, or the fp32
+            // filter has no verdict for it (nearly degenerate, or the eye within rounding of its
+            // plane: the reference's rounding then decides hits anywhere along a line).
+            const float inf = __builtin_huge_valf();
+            float4 box = make_float4(0, inf, 0, inf);
+            const double near_eye = 1e-6 * rho;
+            if (a0z < -near_eye && a1z < -near_eye && a2z < -near_eye && m < 1e300 && !ambiguous) {
+                box = make_float4(0, -1.0f, 0, -1.0f);
+            } else if (a0z > near_eye && a1z > near_eye && a2z > near_eye && m < 1e300 && !ambiguous) {
+                const double X0 = zs * a0x / a0z, X1 = zs * a1x / a1z, X2 = zs * a2x / a2z;
+                const double Y0 = zs * a0y / a0z, Y1 = zs * a1y / a1z, Y2 = zs * a2y / a2z;
+                // only the image matters: |X|, |Y| <= dmax
+                const double x0 = fmax(fmin(X0, fmin(X1, X2)), -dmax), x1 = fmin(fmax(X0, fmax(X1, X2)), dmax);
+                const double y0 = fmax(fmin(Y0, fmin(Y1, Y2)), -dmax), y1 = fmin(fmax(Y0, fmax(Y1, Y2)), dmax);
+                if (x0 > x1 || y0 > y1) {
+                    box = make_float4(0, -1.0f, 0, -1.0f);
+                } else if (x0 == x0 && x1 == x1 && y0 == y0 && y1 == y1) {
+                    const double allow = 0.01 + 9.5367431640625e-07 * dmax;     // pixels
+                    const double xs = (double)RT_RASTER_COLS;
+                    box = make_float4((float)(0.5 * (x0 + x1) / xs),
+                                      (float)((0.5 * (x1 - x0) * 1.0001 + allow) / xs) * 1.0000002f,
+                                      (float)(0.5 * (y0 + y1)),
+                                      (float)(0.5 * (y1 - y0) * 1.0001 + allow) * 1.0000002f);
+                }
+            }
+            squares[i] = box;
+        }
         if (ambiguous) {
             *p[0] = make_float4(0, 0, -1.0f, 0);
             *p[1] = make_float4(0, 0, -1.0f, __builtin_huge_valf());
