@@ -521,44 +521,53 @@ __device__ __forceinline__ void stage_squares(const float4* __restrict__ planes,
     }
 }
 
-// One triangle against the lane's R rays.  First test: is the ray's direction (u, v) inside the
-// triangle's bounding square on the plane of the dominant axis (k_pack_apex),
-//     max(|u - cu|, |v - cv|) <= rho
-// -- two subtractions and a maximum per pair, a three-way minimum per two pairs and one
-// comparison per triangle: 29 VALU instructions per 8 pairs.  A lane with a ray inside goes on
-// to the full inside test with its allowances (finish_apex), from the triangle's four apex
-// planes P, Q, Hh, N, which `planes` fetches (from the LDS tile, or from memory).
+// One triangle against the lane's R rays.  A ray can only hit if its direction (u, v) lies
+// inside the triangle's bounding square on the plane of the dominant axis (k_pack_apex),
+//     max(|u - cu|, |v - cv|) <= rho.
+// First test of every pair: the u half of that, |u - cu| <= rho -- one subtraction per pair, a
+// three-way minimum per two pairs and one comparison per triangle: 13 VALU instructions per 8
+// pairs.  The rays of a wave are a narrow bundle, so few triangles have any of them in their
+// u strip; for those the wave completes the square test, and a lane with a ray inside the
+// square goes on to the full inside test with its allowances (finish_apex), from the
+// triangle's four apex planes P, Q, Hh, N, which `planes` fetches (from the LDS tile, or from
+// memory).
 template <int AX, int R, class Planes>
 __device__ __forceinline__ void apex_triangle(const SweepArgs& A, ApexRay (&ray)[R], long j0, const float4& sq,
                                               int tri, Planes&& planes)
 {
     const float qnan = __builtin_nanf("");
-    float m[R];
+    float du[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-        m[r] = __builtin_fmaxf(__builtin_fabsf(ray[r].u - sq.x), __builtin_fabsf(ray[r].v - sq.y));
-    float mn = m[0];
+    for (int r = 0; r < R; ++r) du[r] = ray[r].u - sq.x;
+    // (a retired ray's NaN is passed over by the minimum)
+    float mn = INF;
+    if (R == 1) mn = __builtin_fabsf(du[0]);
 #pragma unroll
-    for (int r = 1; r < R; ++r) mn = __builtin_fminf(mn, m[r]);     // a retired ray's NaN is passed over
+    for (int r = 0; r + 1 < R; r += 2) mn = min3_abs(mn, du[r], du[r + 1]);
     if (__builtin_expect(mn <= sq.z, 0)) {
-        Tri2 cur;
-        float4 Hh, N;
-        planes(cur, Hh, N);
         unsigned pass = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) pass |= (m[r] <= sq.z ? 1u : 0u) << r;
-        while (pass) {
-            const int rs = __builtin_ctz(pass);
-            pass &= pass - 1;
-            float u = ray[0].u, v = ray[0].v;
+        for (int r = 0; r < R; ++r) {
+            const float m = __builtin_fmaxf(__builtin_fabsf(du[r]), __builtin_fabsf(ray[r].v - sq.y));
+            pass |= (m <= sq.z ? 1u : 0u) << r;
+        }
+        if (pass) {
+            Tri2 cur;
+            float4 Hh, N;
+            planes(cur, Hh, N);
+            while (pass) {
+                const int rs = __builtin_ctz(pass);
+                pass &= pass - 1;
+                float u = ray[0].u, v = ray[0].v;
 #pragma unroll
-            for (int r = 1; r < R; ++r) {
-                u = rs == r ? ray[r].u : u;
-                v = rs == r ? ray[r].v : v;
-            }
-            if (finish_apex<AX>(A, u, v, j0 + (long)rs * 64, tri, cur, Hh, N)) {
+                for (int r = 1; r < R; ++r) {
+                    u = rs == r ? ray[r].u : u;
+                    v = rs == r ? ray[r].v : v;
+                }
+                if (finish_apex<AX>(A, u, v, j0 + (long)rs * 64, tri, cur, Hh, N)) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) ray[r].u = rs == r ? qnan : ray[r].u;
+                    for (int r = 0; r < R; ++r) ray[r].u = rs == r ? qnan : ray[r].u;
+                }
             }
         }
     }
