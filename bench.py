@@ -337,7 +337,7 @@ def main() -> None:
         # the any-hit sweeps of the shadow rays: a third of the frame
         sh_ms, sh_tests = prof.shadow_ms, float(prof.shadow_tests)
         sh_rate = sh_tests / (sh_ms * 1e-3) if sh_ms > 0 else 0.0
-        sh_instr = 29.0 / 8.0                     # hot loop: 29 VALU instructions per 8 pairs (bounding-square test)
+        sh_instr = 13.0 / 8.0                     # hot loop: 13 VALU instructions per 8 pairs (u half of the bounding-square test)
         rp_sh = rocprof_avg_ms(args.workload, f"k_sweep_apex<{spl.value}, false>") if world == 1 else None
         res = {
             "metric": "Mrays/s and ray-tri tests/s (% fp32 peak) at 1/2/4/8 MI355X vs host-CPU ref",
@@ -412,7 +412,7 @@ def main() -> None:
                     "valu_issue": {"instr_per_test": sh_instr, "achieved": sh_rate * sh_instr / 1e12,
                                    "peak": PEAK_VALU_TINSTR, "unit": "T lane-instr/s",
                                    "frac": sh_rate * sh_instr / 1e12 / PEAK_VALU_TINSTR,
-                                   **mix_alone(f"apex{spl.value}_box", sh_rate)},
+                                   **mix_alone(f"apex{spl.value}_strip", sh_rate)},
                     "rays_per_lane": spl.value,
                 },
             },

@@ -80,9 +80,9 @@ constexpr int RT_APEX_SETS = 3 * RT_APEX_LIGHTS;    // ray sets per launch: ligh
 // Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels): the distances of the
 // first pixel and of the row from the box's centre (2 subtractions), one addition for each
 // further pixel, a three-way minimum per two pixels (`logic`) and two compares: 99 instructions
-// per 64 pairs, one flop per pair.  Any-hit apex sweep, per pair: two
-// subtractions and a maximum (the bounding-square test), a three-way minimum per two pairs and a
-// compare per eight: 29 instructions per 8 pairs, 2 flops per pair.
+// per 64 pairs, one flop per pair.  Any-hit apex sweep, per pair: one
+// subtraction (the u half of the bounding-square test), a three-way minimum per two pairs and a
+// compare per eight: 13 instructions per 8 pairs, one flop per pair.
 struct RasterMix { int fma, add, logic, compare; };
 constexpr RasterMix rt_raster_mix(int rpl)
 {
@@ -93,8 +93,8 @@ constexpr double rt_raster_flop_per_pair(int rpl)
 {
     return (2.0 * rt_raster_mix(rpl).fma + rt_raster_mix(rpl).add) / rpl;
 }
-constexpr double RT_APEX_FLOP_PER_PAIR = 2.0;
-constexpr double RT_APEX_INSTR_PER_PAIR = 29.0 / 8.0;
+constexpr double RT_APEX_FLOP_PER_PAIR = 1.0;
+constexpr double RT_APEX_INSTR_PER_PAIR = 13.0 / 8.0;
 
 // per-ray candidate counter written by the sweep: low bits = candidates pushed, plus
 constexpr int RT_CNT_OCCLUDED = 0x40000000;   // any-hit: a certain hit was found
