@@ -369,13 +369,13 @@ def main() -> None:
                       "more frame rendered with it on",
             # Roofline of the dominant kernel, the closest-hit sweep of the primary rays.  It is a
             # vector-ALU kernel: `achieved` counts the fp32 flops its hot loop executes per
-            # ray-triangle pair (FMA = 2, addition = 1; rocprof SQ_INSTS_VALU_{ADD,MUL,FMA}_F32
-            # agree, see profiles/) against the fp32 vector peak.  What actually bounds the loop is
+            # ray-triangle pair (an addition = 1; rocprof SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 agree,
+            # see profiles/) against the fp32 vector peak.  What actually bounds the loop is
             # instruction issue (one VALU instruction per SIMD every two cycles, whatever it
-            # computes): most of its arithmetic is additions that step a plane distance from one
-            # pixel of a lane to the next, so `valu_issue` is the figure that says how close the
-            # kernel is to the machine's limit, and the stated target of half the fp32 flop peak is
-            # not met by construction.
+            # computes): per pair it steps the pixel's distance from the centre of the triangle's
+            # bounding box by one addition and collects two of those in a three-way minimum, so
+            # `valu_issue` is the figure that says how close the kernel is to the machine's limit,
+            # and the stated target of half the fp32 flop peak is not met by construction.
             "roofline": {
                 "bound": "valu-fp32", "kernel": f"k_sweep_raster<{ppl.value}, false> (primary rays, closest hit, all pairs)",
                 "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

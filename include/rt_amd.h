@@ -276,15 +276,16 @@ int rt_apex_sweep_config(int* tile_tris, int* primary_pixels_per_lane,
  * distance from the centre of a triangle's bounding box from one pixel of the lane to the
  * next, and minima that collect them. */
 int rt_raster_sweep_mix(int* pixels_per_lane, int* fma, int* add, int* logic, int* compare);
-/* Tile culling (off by default): before a tile of 128 triangles meets a wave's rays one by one,
- * every triangle of the tile is tested once against the wave's whole bundle -- the pixel
- * rectangle of a primary-ray wave, the direction box of a shadow-ray wave -- with the same
- * conservative edge functions, and only the survivors go through the per-ray tests.  Every
- * wave still visits every triangle and the results are bit for bit the same (the candidates
- * handed to the fp64 pass remain a superset of the true hits); what changes is that most
- * (ray, triangle) pairs are decided a few thousand at a time.  The default keeps the all-pairs
- * sweep of triangle_intersection.cu:167-176, which is what the throughput figures in tests per
- * second refer to.  on: 1 / 0, or -1 to follow the environment variable RT_AMD_CULL again. */
+/* Tile culling (off by default).  The first test of every (ray, triangle) pair is the ray against
+ * the bounding box of the triangle's projection (on the image plane for primary rays, on the
+ * plane of the dominant axis through the light for shadow rays).  With culling on, every
+ * triangle's box is first compared once with a wave's whole bundle -- the pixel rectangle of a
+ * primary-ray wave, the direction box of a shadow-ray wave -- and only the survivors go through
+ * the per-ray tests.  Every wave still visits every triangle and the results are bit for bit the
+ * same (the candidates handed to the fp64 pass are the same); what changes is that most pairs
+ * are decided a few thousand at a time.  The default keeps the all-pairs sweep of
+ * triangle_intersection.cu:167-176, which is what the throughput figures in tests per second
+ * refer to.  on: 1 / 0, or -1 to follow the environment variable RT_AMD_CULL again. */
 int rt_set_tile_culling(int on);
 int rt_get_tile_culling(void);
 int rt_profile_enable(int on);     /* wraps sweep launches in HIP events and reads the device

@@ -795,10 +795,9 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
         RT_TRY(take_counts(slot_next));
         ++slot_next;
     }
-    // ranges grow by 2x; by 4x for fewer than a million rays (what an eighth of a 4K frame sends
-    // through a sweep): their launches are short, and eight of them chain faster than twelve
-    // (35.0 against 36.2 ms for such a part, while the whole frame loses 1.4 ms to the extra tests)
-    const double growth = growth_env > 1.0 ? growth_env : (total < 1000000L ? 4.0 : 2.0);
+    // ranges grow by 2x (4x was measured for the short sweeps of an eighth of a frame: most parts
+    // gain a millisecond, the slowest one and every quarter lose one to the extra tests)
+    const double growth = growth_env > 1.0 ? growth_env : 2.0;
     // a sweep of a few milliseconds is not worth the compaction round trips
     // (RT_AMD_RANGE_MIN_WORK, read at every call: tests set it to 0 to run ranges on small inputs)
     const char* min_work_env = getenv("RT_AMD_RANGE_MIN_WORK");
