@@ -224,12 +224,16 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
             // r = +inf: no bound -- the triangle reaches the eye's plane z = 0, or the fp32
             // filter has no verdict for it (nearly degenerate, or the eye within rounding of its
             // plane: the reference's rounding then decides hits anywhere along a line).
+            // (The reference's fp64 determinants carry errors of about 8 * 2^-53 * rho * l1 * l2 * |D|,
+            // which move a reported hit by up to 8 * 2^-53 * rho^2 * l1 * l2 / |k| in space: with
+            // |k| > 2^-26 rho l1 l2 that is 6e-8 rho, 2e-4 pixel at 4K -- far inside the 0.01.)
             const float inf = __builtin_huge_valf();
             float4 box = make_float4(0, inf, 0, inf);
             const double near_eye = 1e-6 * rho;
-            if (a0z < -near_eye && a1z < -near_eye && a2z < -near_eye && m < 1e300 && !ambiguous) {
+            const bool verdict = m < 1e300 && fabs(k) > 1.4901161193847656e-08 * rho * l1 * l2;      // 2^-26
+            if (a0z < -near_eye && a1z < -near_eye && a2z < -near_eye && verdict) {
                 box = make_float4(0, -1.0f, 0, -1.0f);
-            } else if (a0z > near_eye && a1z > near_eye && a2z > near_eye && m < 1e300 && !ambiguous) {
+            } else if (a0z > near_eye && a1z > near_eye && a2z > near_eye && verdict) {
                 const double X0 = zs * a0x / a0z, X1 = zs * a1x / a1z, X2 = zs * a2x / a2z;
                 const double Y0 = zs * a0y / a0z, Y1 = zs * a1y / a1z, Y2 = zs * a2y / a2z;
                 // only the image matters: |X|, |Y| <= dmax
@@ -279,7 +283,10 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
     // triangle crosses or touches the plane D_kk = 0 inside the pyramid, or it is one of those
     // for which the fp32 filter has no verdict (nearly degenerate, or P within rounding of its
     // plane: the reference's rounding then decides hits anywhere along a line).
-    const bool no_verdict = !(m < 1e300) || !(fabs(k) > 9.3132257461547852e-10 * rho * l1 * l2);     // 2^-30
+    // (The reference's fp64 determinants carry errors of about 8 * 2^-53 * rho * l1 * l2 * |D|, which
+    // move a reported hit by up to 8 * 2^-53 * rho^2 * l1 * l2 / |k| in space: with
+    // |k| > 2^-26 rho l1 l2 that is 6e-8 rho, 1.2e-7 on the unit plane -- inside the 1e-6 below.)
+    const bool no_verdict = !(m < 1e300) || !(fabs(k) > 1.4901161193847656e-08 * rho * l1 * l2);     // 2^-26
     const double A0[3] = {a0x, a0y, a0z}, A1[3] = {a1x, a1y, a1z}, A2[3] = {a2x, a2y, a2z};
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {

@@ -349,7 +349,7 @@ def test_triangles_whose_plane_contains_the_eye(through_eye):
         n /= np.linalg.norm(n)
         b1 = np.cross(n, [0.3, 0.5, 0.8]); b1 /= np.linalg.norm(b1)
         b2 = np.cross(n, b1)
-        off = n * (1e-13 if k % 3 == 0 else 0.0)
+        off = n * (0.0, 1e-13, 1e-9, 1e-7, 1e-5, 1e-3)[k % 6]       # through the eye, or this far off it
         c = b1 * rng.uniform(-8, 8) + b2 * rng.uniform(-8, 8)
         if k % 4 == 0:
             c = c * 0.01            # the eye inside or next to the triangle
@@ -371,6 +371,64 @@ def test_triangles_whose_plane_contains_the_eye(through_eye):
     m = ref["hit"] >= 0
     assert np.array_equal(out["tuv"][m], ref["tuv"][m])
     assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    sc.close()
+
+
+def test_triangles_whose_plane_contains_a_light():
+    """The shadow rays' first test bounds a triangle's projection through the light; a triangle
+    whose plane passes through the light (or within rounding of it), one that surrounds it, and
+    ones that straddle the planes of the three axes through it have no such bound and must be
+    left to the later tests without disturbing the ordinary ones."""
+    rng = np.random.default_rng(7)
+    L = np.array([1.5, 2.0, 14.0])
+    tris = []
+    for k in range(40):             # a floor and clutter that receive shadows
+        c = np.array([rng.uniform(-7, 7), rng.uniform(-5, 5), rng.uniform(16, 26)])
+        e1, e2 = rng.normal(size=3) * 2.5, rng.normal(size=3) * 2.5
+        tris.append([c, c + e1, c + e2])
+    for k in range(24):             # planes through the light, or a little off it
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        b1 = np.cross(n, [0.3, 0.5, 0.8]); b1 /= np.linalg.norm(b1)
+        b2 = np.cross(n, b1)
+        off = n * (0.0, 1e-13, 1e-9, 1e-7, 1e-5, 1e-3)[k % 6]
+        c = L + b1 * rng.uniform(-3, 3) + b2 * rng.uniform(-3, 3)
+        if k % 4 == 0:
+            c = L + (c - L) * 0.01  # the light inside or next to the triangle
+        tris.append([c + off, c + 2 * b1 + off, c + 2 * b2 + off])
+    for k in range(9):              # across the planes x = Lx, y = Ly, z = Lz, near the light and far from it
+        ax = k % 3
+        c = L + rng.normal(size=3) * (0.3 if k < 3 else 4.0)
+        c[ax] = L[ax]
+        e1, e2 = rng.normal(size=3), rng.normal(size=3)
+        tris.append([c - 0.5 * e1, c + e1, c + e2])
+    order = rng.permutation(len(tris))
+    mesh = _eye_space_mesh([tris[i] for i in order])
+    fr = kernel.driver_frame(0)
+    for r in range(4):
+        for c in range(4):
+            fr.obmat[r][c] = fr.obinv[r][c] = 1.0 if r == c else 0.0
+    fr.num_lights = 2
+    for c in range(3):
+        fr.light_in_eye_space[0][c] = L[c]
+        fr.light_in_eye_space[1][c] = (-6.0, 7.0, 3.0)[c]
+    W, H = 128, 80
+    ref, _ = _ref(mesh, fr, W, H)
+    sc, out = _gpu(mesh, fr, W, H)
+    assert (ref["hit"] >= 0).mean() > 0.2 and ref["shadow_rays"] > 2000
+    assert np.array_equal(out["hit"], ref["hit"])
+    assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+    # ... and the same frame with the ranged, sorted and culled paths
+    for env in ({"RT_AMD_RANGE_MIN_WORK": "0"}, {"RT_AMD_RANGE_MIN_WORK": "0", "RT_AMD_CULL": "1"}):
+        import os
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            again = {k: v.cpu().numpy() for k, v in sc.render_rows(fr, W, H, TAN_HALF).items()}
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        assert np.array_equal(again["hit"], out["hit"]) and np.array_equal(again["rgb8"], out["rgb8"]), env
     sc.close()
 
 
