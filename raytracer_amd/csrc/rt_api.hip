@@ -698,7 +698,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     {
         unsigned long long t = 0;
         RT_HIP(hipMemcpy(&t, a.tests, sizeof t, hipMemcpyDeviceToHost));
-        fprintf(stderr, "rt_amd: interval check: %llu slab passes outside the interval\n", t >> 48);
+        fprintf(stderr, "rt_amd: interval check: %llu passes outside the interval\n", t >> 48);
     }
 #endif
 

@@ -1,8 +1,8 @@
-"""The primary sweep's rare path finds a lane's passing pixels as an interval computed from two
-divisions instead of evaluating every pixel of the lane again.  A checking build of the same
-sources (raytracer_amd/librt_amd_check.so, -DRT_RASTER_CHECK_INTERVAL=1) does both and counts
-the slab passes that lie outside the interval; there must be none, on hard scenes and for every
-lane width."""
+"""The primary sweep's rare path finds the pixels of a lane that lie in a triangle's bounding
+box as an interval of pixel numbers (two subtractions) instead of evaluating every pixel of the
+lane again.  A checking build of the same sources (raytracer_amd/librt_amd_check.so,
+-DRT_RASTER_CHECK_INTERVAL=1) does both and counts the pixels the hot loop's own test passes
+that lie outside the interval; there must be none, on hard scenes and for every lane width."""
 import os
 import re
 import subprocess
@@ -34,7 +34,7 @@ for mesh in meshes:
 
 
 @pytest.mark.parametrize("shape", [None, "64,4,1", "32,4,2", "16,3,4", "8,2,1", "32,5,0"])
-def test_no_slab_pass_outside_the_interval(shape):
+def test_no_pass_outside_the_interval(shape):
     if not os.path.exists(CHECK_LIB):
         pytest.fail("raytracer_amd/librt_amd_check.so is missing: run __graft_entry__.build()")
     env = dict(os.environ, RT_AMD_LIB=CHECK_LIB)
@@ -43,6 +43,6 @@ def test_no_slab_pass_outside_the_interval(shape):
     p = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, os.path.join(ROOT, "tools"))], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, p.stderr[-2000:]
-    counts = [int(m) for m in re.findall(r"interval check: (\d+) slab passes", p.stderr)]
+    counts = [int(m) for m in re.findall(r"interval check: (\d+) passes", p.stderr)]
     assert len(counts) >= 16, p.stderr[-2000:]
     assert sum(counts) == 0, counts
