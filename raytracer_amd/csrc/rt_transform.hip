@@ -102,7 +102,8 @@ k_pack(const double* __restrict__ x, const double* __restrict__ y, const double*
 // from P, l = longer edge; the true bound on the fp32 error of U, W', V is about 5 * 2^-24 of
 // that product):
 //     c  = delta * (dmax*|nn| + delta): a pair inside the u slab has U, W' of det's sign and
-//          |U| + |W'| = |det|, hence computed U~ * W~' >= -c.  The sweep's first test.
+//          |U| + |W'| = |det|, hence computed U~ * W~' >= -c.  (The slab product was the any-hit
+//          sweep's first test before the bounding squares below; the sweeps no longer read c.)
 //     m  = 32 * delta: margin of the full inside test (per unit of |det|).
 //     en = 2^-20 * dmax * |nn|: bound on the error of det.
 // A triangle with an exactly zero normal (repeated or proportional vertices) has a zero
