@@ -1,13 +1,14 @@
 // rt_sort.hip -- orders the shadow rays of a set by direction as seen from their light.
 //
-// The any-hit sweep (rt_sweep_apex.hip) pays for a triangle's rare path whenever ANY of a
-// wave's 64 R rays lies in the triangle's u slab.  Rays of neighbouring pixels are neighbours
-// on a smooth surface, but where neighbouring pixels see different depths (a triangle soup,
-// silhouettes) their shadow rays fan out along the light's epipolar lines.  Ordering the rays
-// of a set along a Hilbert curve over the two minor components of D' = D / D_k makes every wave's
-// rays a narrow bundle through the light, which fewer slabs cross, and whose rays tend to
-// share occluders and retire together.  An any-hit query does not depend on the order in
-// which rays are swept, so the results are unchanged.
+// The any-hit sweep (rt_sweep_apex.hip) pays for a triangle's second-level test and rare path
+// whenever ANY of a wave's 64 R rays lies in the u extent of the triangle's bounding square.
+// Rays of neighbouring pixels are neighbours on a smooth surface, but where neighbouring pixels
+// see different depths (a triangle soup, silhouettes) their shadow rays fan out along the
+// light's epipolar lines.  Ordering the rays of a set by the two minor components of
+// D' = D / D_k (u-major, or along a Hilbert curve: see rt_launch_sort_rays) makes every wave's
+// rays a narrow bundle through the light, which fewer triangles' extents meet, and whose rays
+// tend to share occluders and retire together.  An any-hit query does not depend on the order
+// in which rays are swept, so the results are unchanged.
 #include "rt_internal.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -45,7 +46,7 @@ __device__ __forceinline__ unsigned hilbert_index(unsigned x, unsigned y)
 // blockIdx.y = set = light * 3 + dominant axis; ids of set s at ids[s * stride ...], n = counts[s]
 __global__ void __launch_bounds__(RT_WG)
 k_ray_keys(const double* __restrict__ S, const double* __restrict__ E, const int32_t* __restrict__ ids,
-           const int* __restrict__ counts, long stride, KeyArgs ka, unsigned* __restrict__ keys)
+           const int* __restrict__ counts, long stride, KeyArgs ka, int u_major, unsigned* __restrict__ keys)
 {
     const int set = blockIdx.y, light = set / 3, axis = set - 3 * light;
     const int n = counts[set];
@@ -63,7 +64,7 @@ k_ray_keys(const double* __restrict__ S, const double* __restrict__ E, const int
         const float u = (float)(du / dk), v = (float)(dv / dk);
         const unsigned qu = (unsigned)fminf(fmaxf((u + 1.0f) * 2047.5f, 0.0f), 4095.0f);
         const unsigned qv = (unsigned)fminf(fmaxf((v + 1.0f) * 2047.5f, 0.0f), 4095.0f);
-        keys[i] = hilbert_index(qu, qv) | (dk < 0.0 ? 1u << 24 : 0u);
+        keys[i] = (u_major ? (qu << 12) | qv : hilbert_index(qu, qv)) | (dk < 0.0 ? 1u << 24 : 0u);
     }
 }
 
@@ -154,8 +155,14 @@ int rt_launch_sort_rays(rt_scene* sc, const double* S, const double* E, const in
     void* temp = sc->ws_sort.as<char>() + 2 * key_bytes;
     unsigned wgs = (largest + RT_WG - 1) / RT_WG;
     if (wgs > 2048) wgs = 2048;
+    // The all-pairs sweep's first test looks at u alone, so its waves want rays that are close in u
+    // (u-major order: a wave's 512 rays span a few 1e-4 of the u range, whatever their number);
+    // the culled sweep compares a wave's (u, v) box with the triangles' squares and wants compact
+    // boxes (Hilbert order).  RT_AMD_RAY_ORDER=u|hilbert overrides.
+    const char* order_env = getenv("RT_AMD_RAY_ORDER");
+    const int u_major = order_env ? order_env[0] == 'u' : !rt_tile_culling();
     hipLaunchKernelGGL(k_ray_keys, dim3(wgs, sets), dim3(RT_WG), 0, st, S, E, ids_in, counts_dev, stride, ka,
-                       keys_in);
+                       u_major, keys_in);
     RT_HIP(hipGetLastError());
     for (int s = 0; s < sets; ++s) {
         if (counts[s] == 0) continue;
