@@ -37,6 +37,30 @@ def test_ragged_image_sizes(W, H):
     sc.close()
 
 
+@pytest.mark.parametrize("W,H,tan_half", [(8192, 16, TAN_HALF), (3, 4096, TAN_HALF), (96, 64, 10.0), (96, 64, 0.01),
+                                          (640, 40, 1e-4)])
+def test_extreme_image_shapes_and_fields_of_view(W, H, tan_half):
+    """The bounding boxes of the first tests live on the image plane z = (W/2)/tan_half: very wide
+    and very tall images, a field of view of 169 degrees (everything projects near the centre)
+    and of a degree or less (the projection plane is thousands of pixels away and most of the mesh
+    falls outside the image)."""
+    for mesh in (scenes.torus(600), scenes.triangle_soup(500, seed=3)):
+        fr = kernel.driver_frame(5)
+        X, Y, Z = O.transform(mesh, kernel.frame_matrix(fr, "obmat"))
+        ref = O.render_rows(O.Scene(mesh, X, Y, Z), O.frame_from(fr), W, H, tan_half)
+        sc = kernel.Scene(mesh)
+        sc.transform(kernel.frame_matrix(fr, "obmat"))
+        for cull in (False, True):
+            kernel.set_tile_culling(cull)
+            try:
+                out = {k: v.cpu().numpy() for k, v in sc.render_rows(fr, W, H, tan_half).items()}
+            finally:
+                kernel.set_tile_culling(None)
+            assert np.array_equal(out["hit"], ref["hit"]), (mesh.name, cull)
+            assert np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int)).max() <= 1
+        sc.close()
+
+
 @pytest.mark.parametrize("ntris", [1, 2, 127, 128, 129, 257])
 def test_triangle_counts_around_the_tile_size(ntris):
     mesh = scenes.triangle_soup(ntris, seed=ntris)
