@@ -77,6 +77,18 @@ constexpr int kRasterUnroll = RT_RASTER_UNROLL;
 constexpr int kApexUnroll = RT_APEX_UNROLL;
 
 struct Tri2 { float4 P, Q; };
+// LDS by its 32-bit address (a float4 of HIP is a class, which a pointer into another address
+// space cannot be dereferenced as; the native vector can)
+typedef float native_float4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_address(const void* p)
+{
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ float4 lds_read_float4(unsigned at)
+{
+    const native_float4 v = *(const __attribute__((address_space(3))) native_float4*)(size_t)at;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 __device__ __forceinline__ Tri2 load_tri2(const float4* p) { return {p[0], p[RT_TILE]}; }
 
@@ -617,19 +629,30 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
         const int buf = (t - t_begin) & 1;
         if (t + 1 < t_end) stage_light_tile<AX>(A.planes, A.plane_stride, t + 1, tile[buf ^ 1], wave, lane);
         const float4* __restrict__ base = tile[buf][0];
-        const float4* __restrict__ squares = tile[buf][RT_APEX_PLANES];
         const int tri0 = t * RT_TILE;
-        // LDS reads are issued one triangle ahead by hand
-        float4 next = squares[0];
-#pragma unroll kApexUnroll
-        for (int j = 0; j < RT_TILE; ++j) {
-            const float4 sq = next;
-            next = squares[(j + 1) & (RT_TILE - 1)];
-            apex_triangle<AX, R>(A, ray, j0, sq, tri0 + j, [&](Tri2& cur, float4& Hh, float4& N) {
-                cur = load_tri2(base + j);
-                Hh = base[j + 2 * RT_TILE];
-                N = base[j + 3 * RT_TILE];
-            });
+        // The squares are read at wave-uniform addresses, which the compiler would form in scalar
+        // registers and copy to a vector register before every read (one VALU instruction per
+        // triangle beside the loop's 13).  Held in a vector register the compiler cannot see
+        // through, the address advances once per kApexUnroll triangles and the reads use
+        // immediate offsets.  Reads are issued one triangle ahead by hand; the last one of a
+        // tile reads the entry behind the plane (the next buffer's first, or the padding behind
+        // the tile buffers) and is not used.
+        unsigned sq_at = lds_address(tile[buf][RT_APEX_PLANES]);
+        asm volatile("" : "+v"(sq_at));
+        float4 next = lds_read_float4(sq_at);
+        for (int j4 = 0; j4 < RT_TILE; j4 += kApexUnroll) {
+#pragma unroll
+            for (int k = 0; k < kApexUnroll; ++k) {
+                const int j = j4 + k;
+                const float4 sq = next;
+                next = lds_read_float4(sq_at + 16u * (unsigned)(k + 1));
+                apex_triangle<AX, R>(A, ray, j0, sq, tri0 + j, [&](Tri2& cur, float4& Hh, float4& N) {
+                    cur = load_tri2(base + j);
+                    Hh = base[j + 2 * RT_TILE];
+                    N = base[j + 3 * RT_TILE];
+                });
+            }
+            sq_at += 16u * kApexUnroll;
         }
         ++tiles_done;
         __builtin_amdgcn_s_waitcnt(0);
@@ -696,7 +719,8 @@ __global__ void __launch_bounds__(RT_WG, R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES)
 {
     // all pairs: two buffers of one tile's five planes; tile culling: two of a group's squares
     constexpr int kTileFloat4 = CULL ? RT_CULL_GROUP * RT_TILE : (RT_APEX_PLANES + 1) * RT_TILE;
-    __shared__ float4 lds[2][kTileFloat4];
+    // (one more entry: the read-ahead of the all-pairs loop touches the one behind the second buffer)
+    __shared__ float4 lds[2 * kTileFloat4 + 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -1,5 +1,5 @@
 """Prints the kernel timeline of the last frame in a rocprofv3 kernel trace of tools/part_trace.py
-(development aid): part_timeline.py <kernel_trace.csv>"""
+(development aid): part_timeline.py <kernel_trace.csv> [all]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -13,7 +13,7 @@ for r in rows[idx:]:
     prev_end = e
     busy += e - s
     n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:28]
-    if (e - s) > 20000 or gap > 10:
+    if len(sys.argv) > 2 or (e - s) > 20000 or gap > 10:
         print(f"{(s-t0)/1e6:8.3f} ms  gap {gap:7.1f} us  dur {(e-s)/1e6:7.3f} ms  grid "
               f"{int(r['Grid_Size_X'])//int(r['Workgroup_Size_X']):5d} x {r['Grid_Size_Y']:>3} x {r['Grid_Size_Z']:>3}  {n}")
 print(f"frame {(prev_end-t0)/1e6:.3f} ms, kernels busy {busy/1e6:.3f} ms")
