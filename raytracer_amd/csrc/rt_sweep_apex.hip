@@ -173,7 +173,8 @@ __device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4
     float acc = INF;
     if (R == 1) acc = __builtin_fabsf(d0);
 #pragma unroll
-    for (int r = 0; r + 1 < R; r += 2) acc = min3_abs(acc, d0 + (float)r, d0 + (float)(r + 1));
+    for (int r = 0; r + 1 < R; r += 2)      // (d0 + 0.0f is not d0 to the compiler: it would keep the addition)
+        acc = min3_abs(acc, r == 0 ? d0 : d0 + (float)r, d0 + (float)(r + 1));
     if (__builtin_expect(acc <= box.y && __builtin_fabsf(Y - box.z) <= box.w, 0)) {
         // the pixels of the box: r with |d0 + r| <= rx, one more on either side for the rounding
         // of these two bounds (the inside test decides about every pixel it is given)
@@ -234,7 +235,9 @@ __device__ __forceinline__ void stage_boxes(const float4* __restrict__ boxes, in
 template <int R, bool CULL>
 __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const SweepArgs A)
 {
-    __shared__ float4 tile[2][RT_CULL_GROUP * RT_TILE];
+    // (one more entry: the read-ahead of the all-pairs loop touches the one behind the second buffer)
+    __shared__ float4 tile_lds[2 * RT_CULL_GROUP * RT_TILE + 1];
+    auto tile = reinterpret_cast<float4 (*)[RT_CULL_GROUP * RT_TILE]>(tile_lds);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -330,13 +333,21 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
             // LDS reads are issued one triangle ahead by hand (the rare path splits the body into
             // basic blocks, which keeps the compiler from hoisting them)
             for (int sub = 0; wave_on && sub < count; ++sub) {
-                const float4* __restrict__ b = base + sub * RT_TILE;
-                float4 next = b[0];
-#pragma unroll kRasterUnroll
-                for (int j = 0; j < RT_TILE; ++j) {
-                    const float4 box = next;
-                    next = b[(j + 1) & (RT_TILE - 1)];      // the last iteration re-reads entry 0 (unused)
-                    raster_triangle<R>(A, box, tri0 + sub * RT_TILE + j, Xs0, Y, on_image, slot0);
+                // (the address in a vector register the compiler cannot see through, advanced once
+                // per kRasterUnroll triangles, the reads at immediate offsets: formed in scalar
+                // registers it would be copied to a vector register before every read; the last
+                // read of a tile touches the entry behind it and is not used)
+                unsigned box_at = lds_address(base + sub * RT_TILE);
+                asm volatile("" : "+v"(box_at));
+                float4 next = lds_read_float4(box_at);
+                for (int j4 = 0; j4 < RT_TILE; j4 += kRasterUnroll) {
+#pragma unroll
+                    for (int k = 0; k < kRasterUnroll; ++k) {
+                        const float4 box = next;
+                        next = lds_read_float4(box_at + 16u * (unsigned)(k + 1));
+                        raster_triangle<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, Y, on_image, slot0);
+                    }
+                    box_at += 16u * kRasterUnroll;
                 }
             }
         }
