@@ -647,7 +647,7 @@ static int lights_launch(rt_scene* sc, const rt_frame* f, int lights);
 // scene's side stream beside the sweep (see lights_fork / lights_launch)
 static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const RowMap& rows,
                               int32_t* hit, double* tuv, const rt_frame* aside_frame = nullptr,
-                              int aside_lights = 0)
+                              int aside_lights = 0, bool wait = true)
 {
     RtGlobal& g = rt_g();
     hipStream_t st = g.stream;
@@ -708,7 +708,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     RT_TRY(rt_launch_overflow_primary(es, W, H, tan_half, rows, sc->ws_ovf.as<int32_t>(), counters,
                                       hit, tuv, sc->ws_partials.p, st));
     RT_TRY(fetch_counters(counters, false));
-    RT_HIP(hipStreamSynchronize(st));
+    if (wait) RT_HIP(hipStreamSynchronize(st));     // (the pixel loop goes on queueing behind it instead)
     return RT_OK;
 }
 
@@ -1127,10 +1127,8 @@ static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, doubl
     // the first group of lights is sorted and packed on a side stream beside the primary sweep
     static const bool aside_env = !(getenv("RT_AMD_LIGHTS_ASIDE") && atoi(getenv("RT_AMD_LIGHTS_ASIDE")) == 0);
     const bool aside = L > 0 && aside_env;
-    RT_TRY(trace_primary_rows(sc, W, H, tan_half, rows, hit, tuv, aside ? f : nullptr,
-                              L < RT_APEX_LIGHTS ? L : RT_APEX_LIGHTS));
-
-    // frame constants
+    // frame constants: uploaded ahead of the sweep, so that nothing between the sweep and the
+    // shading kernels has to wait for the host
     DevBuf& frame_dev = sc->ws_frame;
     RT_TRY(frame_dev.reserve(sizeof(DevFrame)));
     sc->frame_host.resize(sizeof(DevFrame));        // kept with the scene: outlives the async copy below
@@ -1143,7 +1141,9 @@ static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, doubl
     memcpy(hf.light_att, f->light_attenuation, sizeof hf.light_att);
     memcpy(hf.light_max, f->light_max_dist, sizeof hf.light_max);
     RT_HIP(hipMemcpyAsync(frame_dev.p, &hf, sizeof hf, hipMemcpyHostToDevice, st));
-    RT_HIP(hipStreamSynchronize(st));
+
+    RT_TRY(trace_primary_rows(sc, W, H, tan_half, rows, hit, tuv, aside ? f : nullptr,
+                              L < RT_APEX_LIGHTS ? L : RT_APEX_LIGHTS, false));
 
     ShadeArgs a{};
     a.es = exact_of(sc);

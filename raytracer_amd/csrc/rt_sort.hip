@@ -43,10 +43,15 @@ __device__ __forceinline__ unsigned hilbert_index(unsigned x, unsigned y)
     return d;
 }
 
-// blockIdx.y = set = light * 3 + dominant axis; ids of set s at ids[s * stride ...], n = counts[s]
+// blockIdx.y = set = light * 3 + dominant axis; ids of set s at ids[s * stride ...], n = counts[s].
+// The sets are sorted in one pass over all of them: a ray's key carries its set above the 25 bits
+// of its direction, and keys and ray numbers are written back to back (set s from key_off[s] on).
+constexpr unsigned kRayKeyBits = 25;
+
 __global__ void __launch_bounds__(RT_WG)
 k_ray_keys(const double* __restrict__ S, const double* __restrict__ E, const int32_t* __restrict__ ids,
-           const int* __restrict__ counts, long stride, KeyArgs ka, int u_major, unsigned* __restrict__ keys)
+           const int* __restrict__ counts, long stride, KeyArgs ka, int u_major, unsigned* __restrict__ keys,
+           int32_t* __restrict__ vals)
 {
     const int set = blockIdx.y, light = set / 3, axis = set - 3 * light;
     const int n = counts[set];
@@ -54,6 +59,7 @@ k_ray_keys(const double* __restrict__ S, const double* __restrict__ E, const int
     E += 3 * light * stride;
     ids += set * stride;
     keys += ka.key_off[set];
+    vals += ka.key_off[set];
     for (int i = blockIdx.x * RT_WG + threadIdx.x; i < n; i += gridDim.x * RT_WG) {
         const long id = ids[i];
         const double dx = E[3 * id] - S[3 * id], dy = E[3 * id + 1] - S[3 * id + 1],
@@ -64,8 +70,21 @@ k_ray_keys(const double* __restrict__ S, const double* __restrict__ E, const int
         const float u = (float)(du / dk), v = (float)(dv / dk);
         const unsigned qu = (unsigned)fminf(fmaxf((u + 1.0f) * 2047.5f, 0.0f), 4095.0f);
         const unsigned qv = (unsigned)fminf(fmaxf((v + 1.0f) * 2047.5f, 0.0f), 4095.0f);
-        keys[i] = (u_major ? (qu << 12) | qv : hilbert_index(qu, qv)) | (dk < 0.0 ? 1u << 24 : 0u);
+        keys[i] = (u_major ? (qu << 12) | qv : hilbert_index(qu, qv)) | (dk < 0.0 ? 1u << 24 : 0u) |
+                  ((unsigned)set << kRayKeyBits);
+        vals[i] = (int32_t)id;
     }
+}
+
+// The sorted ray numbers back into the sets' own lists: set s to out[s * stride ...].
+__global__ void __launch_bounds__(RT_WG)
+k_unpack_sets(const int32_t* __restrict__ vals, const int* __restrict__ counts, long stride, KeyArgs ka,
+              int32_t* __restrict__ out)
+{
+    const int set = blockIdx.y, n = counts[set];
+    vals += ka.key_off[set];
+    out += set * stride;
+    for (int i = blockIdx.x * RT_WG + threadIdx.x; i < n; i += gridDim.x * RT_WG) out[i] = vals[i];
 }
 
 // Solid angle a triangle subtends at the apex (Van Oosterom and Strackee), as a sort key: the
@@ -142,17 +161,26 @@ int rt_launch_sort_rays(rt_scene* sc, const double* S, const double* E, const in
         if ((unsigned)counts[s] > largest) largest = (unsigned)counts[s];
     }
     if (total == 0) return RT_OK;
+    // one sort over all sets (the set number above the direction bits of the key): a radix sort
+    // of a few hundred thousand keys is a chain of small launches, and a chain per set made the
+    // ordering of a row part's rays cost 0.7 ms of launch latency per frame
+    unsigned set_bits = 0;
+    while ((1 << set_bits) < sets) ++set_bits;
+    const unsigned end_bit = kRayKeyBits + set_bits;
     size_t temp_bytes = 0;
     if (rocprim::radix_sort_pairs(nullptr, temp_bytes, (unsigned*)nullptr, (unsigned*)nullptr,
-                                  (int32_t*)nullptr, (int32_t*)nullptr, largest, 0u, 25u, st) != hipSuccess) {
+                                  (int32_t*)nullptr, (int32_t*)nullptr, (unsigned)total, 0u, end_bit, st) != hipSuccess) {
         rt_set_error("ray sort: size query failed");
         return RT_E_HIP;
     }
-    const size_t key_bytes = ((size_t)total * sizeof(unsigned) + 255) & ~(size_t)255;
-    if (int rc = sc->ws_sort.reserve(2 * key_bytes + temp_bytes)) return rc;
-    unsigned* keys_in = sc->ws_sort.as<unsigned>();
-    unsigned* keys_out = reinterpret_cast<unsigned*>(sc->ws_sort.as<char>() + key_bytes);
-    void* temp = sc->ws_sort.as<char>() + 2 * key_bytes;
+    const size_t arr = ((size_t)total * sizeof(unsigned) + 255) & ~(size_t)255;
+    if (int rc = sc->ws_sort.reserve(4 * arr + temp_bytes)) return rc;
+    char* ws = sc->ws_sort.as<char>();
+    unsigned* keys_in = reinterpret_cast<unsigned*>(ws);
+    unsigned* keys_out = reinterpret_cast<unsigned*>(ws + arr);
+    int32_t* vals_in = reinterpret_cast<int32_t*>(ws + 2 * arr);
+    int32_t* vals_out = reinterpret_cast<int32_t*>(ws + 3 * arr);
+    void* temp = ws + 4 * arr;
     unsigned wgs = (largest + RT_WG - 1) / RT_WG;
     if (wgs > 2048) wgs = 2048;
     // Hilbert order over (u, v).  RT_AMD_RAY_ORDER=u: u-major instead, which suits the all-pairs
@@ -163,14 +191,12 @@ int rt_launch_sort_rays(rt_scene* sc, const double* S, const double* E, const in
     const char* order_env = getenv("RT_AMD_RAY_ORDER");
     const int u_major = order_env && order_env[0] == 'u';
     hipLaunchKernelGGL(k_ray_keys, dim3(wgs, sets), dim3(RT_WG), 0, st, S, E, ids_in, counts_dev, stride, ka,
-                       u_major, keys_in);
+                       u_major, keys_in, vals_in);
     RT_HIP(hipGetLastError());
-    for (int s = 0; s < sets; ++s) {
-        if (counts[s] == 0) continue;
-        size_t bytes = temp_bytes;
-        RT_HIP(rocprim::radix_sort_pairs(temp, bytes, keys_in + ka.key_off[s], keys_out + ka.key_off[s],
-                                         ids_in + s * stride, ids_out + s * stride, (unsigned)counts[s],
-                                         0u, 25u, st));
-    }
+    RT_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (unsigned)total, 0u,
+                                     end_bit, st));
+    hipLaunchKernelGGL(k_unpack_sets, dim3(wgs, sets), dim3(RT_WG), 0, st, vals_out, counts_dev, stride, ka,
+                       ids_out);
+    RT_HIP(hipGetLastError());
     return RT_OK;
 }
