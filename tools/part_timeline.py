@@ -3,7 +3,11 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_sweep_raster" in r["Kernel_Name"]][-1]
+# the last frame: from the last primary sweep that follows a shading kernel (a frame may have two sweeps)
+sweeps = [i for i, r in enumerate(rows) if "k_sweep_raster" in r["Kernel_Name"]]
+shades = [i for i, r in enumerate(rows) if "k_shade_final" in r["Kernel_Name"]]
+ends = [i for i in shades if any(j > i for j in sweeps)]
+idx = min(j for j in sweeps if j > ends[-1]) if ends else sweeps[0]
 t0 = int(rows[idx]["Start_Timestamp"])
 prev_end = None
 busy = 0
