@@ -119,6 +119,20 @@ __device__ __forceinline__ float min3_abs(float a, float b, float c)
     return r;
 }
 
+// max(|a|, |b|) and min(a, b, c), likewise one instruction each
+__device__ __forceinline__ float max_abs(float a, float b)
+{
+    float r;
+    asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float min3_plain(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // The inside test for one pixel that lies in the bounding box of triangle `tri` (candidate() of
 // rt_sweep_common.h with the bookkeeping in memory).  Xs = the pixel's X / RT_RASTER_COLS;
 // P, Hh, N = the triangle's planes 0, 2, 3 (sign layout of k_pack_apex), margin = plane 1's w.
@@ -568,13 +582,20 @@ __device__ __forceinline__ void apex_triangle(const SweepArgs& A, ApexRay (&ray)
 #pragma unroll
     for (int r = 0; r + 1 < R; r += 2) mn = min3_abs(mn, du[r], du[r + 1]);
     if (__builtin_expect(mn <= sq.z, 0)) {
-        unsigned pass = 0;
+        // second level, for the lanes with a ray in the u strip: the square test completed the
+        // same way (a subtraction and a maximum per ray, a three-way minimum per two rays, one
+        // comparison); which rays are inside is only worked out when one is
+        float m[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float m = __builtin_fmaxf(__builtin_fabsf(du[r]), __builtin_fabsf(ray[r].v - sq.y));
-            pass |= (m <= sq.z ? 1u : 0u) << r;
-        }
-        if (pass) {
+        for (int r = 0; r < R; ++r) m[r] = max_abs(du[r], ray[r].v - sq.y);
+        float mn2 = INF;
+        if (R == 1) mn2 = m[0];
+#pragma unroll
+        for (int r = 0; r + 1 < R; r += 2) mn2 = min3_plain(mn2, m[r], m[r + 1]);
+        if (mn2 <= sq.z) {
+            unsigned pass = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) pass |= (m[r] <= sq.z ? 1u : 0u) << r;
             Tri2 cur;
             float4 Hh, N;
             planes(cur, Hh, N);
@@ -588,8 +609,12 @@ __device__ __forceinline__ void apex_triangle(const SweepArgs& A, ApexRay (&ray)
                     v = rs == r ? ray[r].v : v;
                 }
                 if (finish_apex<AX>(A, u, v, j0 + (long)rs * 64, tri, cur, Hh, N)) {
+                    // (both components: the maximum above passes over a single NaN)
 #pragma unroll
-                    for (int r = 0; r < R; ++r) ray[r].u = rs == r ? qnan : ray[r].u;
+                    for (int r = 0; r < R; ++r) {
+                        ray[r].u = rs == r ? qnan : ray[r].u;
+                        ray[r].v = rs == r ? qnan : ray[r].v;
+                    }
                 }
             }
         }
@@ -609,7 +634,7 @@ __device__ __forceinline__ bool apex_all_retired(const SweepArgs& A, ApexRay (&r
         if (poll && ray[r].u == ray[r].u &&
             (__hip_atomic_load(&A.cnt[A.active[j0 + r * 64]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
              RT_CNT_OCCLUDED))
-            ray[r].u = qnan;
+            ray[r].u = ray[r].v = qnan;
         done = done && !(ray[r].u == ray[r].u);
     }
     return __syncthreads_and(done);
