@@ -77,16 +77,21 @@ constexpr int RT_APEX_PLANES = 4;
 constexpr int RT_LIGHT_PLANES = RT_APEX_PLANES + 3;
 constexpr int RT_APEX_LIGHTS = 4;   // lights swept per any-hit launch (plane sets kept side by side)
 constexpr int RT_APEX_SETS = 3 * RT_APEX_LIGHTS;    // ray sets per launch: light x dominant axis
-// Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels): the distances of the
-// first pixel and of the row from the box's centre (2 subtractions), one addition for each
-// further pixel, a three-way minimum per two pixels (`logic`) and two compares: 99 instructions
-// per 64 pairs, one flop per pair.  Any-hit apex sweep, per pair: one
-// subtraction (the u half of the bounding-square test), a three-way minimum per two pairs and a
-// compare per eight: 13 instructions per 8 pairs, one flop per pair.
+// A lane's rpl pixels in the pixel-grid sweep are a block of this many rows (by rpl / rows columns).
+constexpr int rt_raster_lane_rows(int rpl) { return rpl >= 64 ? 8 : (rpl >= 16 ? 4 : (rpl >= 4 ? 2 : 1)); }
+// Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels = rows x columns): the
+// distance of the first column from the box's centre and one addition for each further column,
+// one subtraction per row, a three-way minimum per two columns and per two rows (`logic`) and
+// two compares: 26 instructions per 64 pairs (8 x 8), a quarter of a flop per pair.  Any-hit apex
+// sweep, per pair: one subtraction (the u half of the bounding-square test), a three-way minimum
+// per two pairs and a compare per eight: 13 instructions per 8 pairs, one flop per pair.
 struct RasterMix { int fma, add, logic, compare; };
 constexpr RasterMix rt_raster_mix(int rpl)
 {
-    return RasterMix{0, rpl + 1, rpl > 1 ? rpl / 2 : 0, 2};
+    return RasterMix{0, rpl / rt_raster_lane_rows(rpl) + rt_raster_lane_rows(rpl),
+                     (rpl / rt_raster_lane_rows(rpl) > 1 ? rpl / rt_raster_lane_rows(rpl) / 2 : 0) +
+                         (rt_raster_lane_rows(rpl) > 1 ? rt_raster_lane_rows(rpl) / 2 : 0),
+                     2};
 }
 // fp32 flops per pair (FMA = 2) of that loop
 constexpr double rt_raster_flop_per_pair(int rpl)

@@ -67,7 +67,8 @@
 #define RT_RASTER_CHECK_INTERVAL 0   // debug: count slab passes the rare path's interval would miss
 #endif
 #ifndef RT_RASTER_WAVES
-#define RT_RASTER_WAVES RT_MIN_WAVES    // waves per SIMD the pixel-grid sweep must fit
+#define RT_RASTER_WAVES 8   // waves per SIMD the pixel-grid sweep must fit (64 registers: the rare path
+                            // spills a few, the hot loop gains 3 % over six waves at 76)
 #endif
 
 namespace {
@@ -172,46 +173,67 @@ __device__ __forceinline__ void finish_raster(const SweepArgs& A, long slot, int
         atomicMin(reinterpret_cast<int*>(A.best_hi + slot), __float_as_int(t + terr));
 }
 
-// One triangle against the R pixels of a lane.  box = (cx, rx, cy, ry): the triangle's bounding
-// box on the pixel grid, x in units of RT_RASTER_COLS pixels (k_pack_apex).  First test of every
-// pair: |Xs - cx| <= rx, with Xs - cx stepping by one from pixel to pixel of the lane -- one
-// addition per pixel and one three-way minimum per two pixels; the row test |Y - cy| <= ry is
-// the lane's.  A lane with a pixel inside fetches the triangle's planes from memory (tri is
-// wave-uniform) and runs the inside test on the pixels of the box.
+// One triangle against the R pixels of a lane, a block of RY rows by RX columns (the columns
+// RT_RASTER_COLS pixels apart).  box = (cx, rx, cy, ry): the triangle's bounding box on the pixel
+// grid, x in units of RT_RASTER_COLS pixels (k_pack_apex).  A pixel lies in the box when its
+// column lies in the box's x extent and its row in the y extent, so the first test of the lane's
+// R pairs is one interval test per column, |Xs - cx| <= rx (Xs - cx steps by one from column to
+// column: one addition each), one per row, |Y - cy| <= ry (one subtraction each), and a
+// three-way minimum per two of either: some pixel of the block is in the box exactly when some
+// column and some row are.  A lane with a pixel inside fetches the triangle's planes from memory
+// (tri is wave-uniform) and runs the inside test on the pixels of the box.
 template <int R>
-__device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4& box, int tri, float Xs0, float Y,
+__device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4& box, int tri, float Xs0,
+                                                const float (&Y)[rt_raster_lane_rows(R)],
                                                 unsigned long long on_image, long slot0)
 {
     constexpr int COLS = RT_RASTER_COLS;
+    constexpr int RY = rt_raster_lane_rows(R), RX = R / RY;
     const float d0 = Xs0 - box.x;
-    float acc = INF;
-    if (R == 1) acc = __builtin_fabsf(d0);
+    float accx = INF;
+    if (RX == 1) accx = __builtin_fabsf(d0);
 #pragma unroll
-    for (int r = 0; r + 1 < R; r += 2)      // (d0 + 0.0f is not d0 to the compiler: it would keep the addition)
-        acc = min3_abs(acc, r == 0 ? d0 : d0 + (float)r, d0 + (float)(r + 1));
-    if (__builtin_expect(acc <= box.y && __builtin_fabsf(Y - box.z) <= box.w, 0)) {
-        // the pixels of the box: r with |d0 + r| <= rx, one more on either side for the rounding
+    for (int c = 0; c + 1 < RX; c += 2)     // (d0 + 0.0f is not d0 to the compiler: it would keep the addition)
+        accx = min3_abs(accx, c == 0 ? d0 : d0 + (float)c, d0 + (float)(c + 1));
+    float dy[RY];
+#pragma unroll
+    for (int j = 0; j < RY; ++j) dy[j] = Y[j] - box.z;      // (a row beyond the band has Y = NaN and never passes)
+    float accy = INF;
+    if (RY == 1) accy = __builtin_fabsf(dy[0]);
+#pragma unroll
+    for (int j = 0; j + 1 < RY; j += 2) accy = min3_abs(accy, dy[j], dy[j + 1]);
+    if (__builtin_expect(accx <= box.y && accy <= box.w, 0)) {
+        // the columns of the box: c with |d0 + c| <= rx, one more on either side for the rounding
         // of these two bounds (the inside test decides about every pixel it is given)
-        int r = (int)__builtin_floorf(__builtin_fmaxf(-box.y - d0, 0.0f)) - 1;
-        int r_hi = (int)__builtin_ceilf(__builtin_fminf(box.y - d0, (float)(R - 1))) + 1;
-        r = r < 0 ? 0 : r;
-        r_hi = r_hi > R - 1 ? R - 1 : r_hi;
+        int c_lo = (int)__builtin_floorf(__builtin_fmaxf(-box.y - d0, 0.0f)) - 1;
+        int c_hi = (int)__builtin_ceilf(__builtin_fminf(box.y - d0, (float)(RX - 1))) + 1;
+        c_lo = c_lo < 0 ? 0 : c_lo;
+        c_hi = c_hi > RX - 1 ? RX - 1 : c_hi;
 #if RT_RASTER_CHECK_INTERVAL
         {
-            unsigned long long pass = 0;
+            unsigned pass = 0;
 #pragma unroll
-            for (int k = 0; k < R; ++k)
-                pass |= (unsigned long long)(__builtin_fabsf(d0 + (float)k) <= box.y ? 1 : 0) << k;
-            const unsigned long long inside =
-                r > r_hi ? 0ull : ((r_hi >= 63 ? ~0ull : (2ull << r_hi) - 1ull) & ~((1ull << r) - 1ull));
+            for (int k = 0; k < RX; ++k) pass |= (__builtin_fabsf(d0 + (float)k) <= box.y ? 1u : 0u) << k;
+            const unsigned inside = c_lo > c_hi ? 0u : (((2u << c_hi) - 1u) & ~((1u << c_lo) - 1u));
             if ((pass & ~inside) && A.tests) atomicAdd(A.tests, 1ull << 48);
         }
 #endif
         const float4* __restrict__ g = A.planes + tri;
         const float4 P = g[0], Hh = g[2 * A.plane_stride], N = g[3 * A.plane_stride];
         const float margin = g[A.plane_stride].w;
-        for (; r <= r_hi; ++r)
-            if ((on_image >> r) & 1ull) finish_raster(A, slot0 + COLS * r, tri, P, margin, Hh, N, Xs0 + (float)r, Y);
+        unsigned rows_in = 0;           // the rows of the box: each row's own first test
+#pragma unroll
+        for (int j = 0; j < RY; ++j) rows_in |= (__builtin_fabsf(dy[j]) <= box.w ? 1u : 0u) << j;
+        while (rows_in) {
+            const int j = __builtin_ctz(rows_in);
+            rows_in &= rows_in - 1;
+            float Yj = Y[0];
+#pragma unroll
+            for (int k = 1; k < RY; ++k) Yj = j == k ? Y[k] : Yj;
+            for (int c = c_lo; c <= c_hi; ++c)
+                if ((on_image >> (j * RX + c)) & 1ull)
+                    finish_raster(A, slot0 + (long)j * A.W + COLS * c, tri, P, margin, Hh, N, Xs0 + (float)c, Yj);
+        }
     }
 }
 
@@ -257,11 +279,15 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    // wave = (COLS R) x (64 / COLS) pixels; lane = one row, R pixels COLS apart; workgroup = its
-    // four waves side by side ((16 R) x 16 pixels), two by two or stacked.  (The squarer a wave's
-    // pixels, the fewer triangles have one of them in their box: the rare path is paid per wave.)
+    // wave = (COLS R) x (64 / COLS) pixels; workgroup = its four waves side by side ((16 R) x 16
+    // pixels), two by two or stacked.  (The squarer a wave's pixels, the fewer triangles have one
+    // of them in their box: the rare path is paid per wave.)  A lane's R pixels are a block of RY
+    // rows by RX columns COLS pixels apart: RY such blocks side by side, each four lanes wide
+    // (the column phases), fill the wave's width, 16 / RY rows of blocks its height.
     constexpr int COLS = RT_RASTER_COLS;
+    constexpr int RY = rt_raster_lane_rows(R), RX = R / RY;
     static_assert(64 / COLS == RT_TILE_H, "a wave covers RT_TILE_H rows");
+    static_assert(RT_TILE_H % RY == 0 && R % RY == 0, "a lane's block divides the wave's pixels");
     // the four waves: waves_x side by side, the rest below (whichever wastes fewer pixels beyond
     // the image's right and bottom edges)
     // ... or, waves_x = 0, the wave-sized blocks of the band numbered row by row and dealt four
@@ -279,21 +305,27 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
         wave_x0 = txi * tile_w + (wave & (wx - 1)) * (COLS * R);
         wave_y0 = tyi * tile_h + (wave / wx) * RT_TILE_H;
     }
-    const int px0 = wave_x0 + (lane % COLS);
-    const int lr = wave_y0 + lane / COLS;                           // local row of the call's row set
+    const int block = lane / COLS;                                  // 0 .. 15: which block of the wave
+    const int px0 = wave_x0 + (block % RY) * (COLS * RX) + (lane % COLS);
+    const int lr0 = wave_y0 + (block / RY) * RY;                    // first local row of the call's row set
     // a wave that lies wholly beyond the image's right or bottom edge only helps to stage tiles
     const bool wave_on = __builtin_amdgcn_readfirstlane((wave_x0 < A.W && wave_y0 < A.rows.rows) ? 1 : 0) != 0;
-    const float Y = (float)(A.rows.image_row(lr) - A.H / 2);        // driver.c:132
-    // ray number: local pixel (the triangle chunks of a pixel share its count, list and bound)
-    const long slot0 = (long)lr * A.W + px0;
-
-    // pixel r of the lane has X = px0 + COLS r - W/2 (driver.c:131); the planes and boxes are in
-    // units of COLS pixels, so the sweep works with X / COLS = Xs0 + r (exact in fp32)
-    const float Xs0 = (float)(px0 - A.W / 2) * (1.0f / COLS);
-    unsigned long long on_image = 0;        // bit r: pixel r of the lane exists
+    float Y[RY];                                                    // driver.c:132; NaN for a row beyond the band
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-        on_image |= ((px0 + COLS * r < A.W) && (lr < A.rows.rows) ? 1ull : 0ull) << r;
+    for (int j = 0; j < RY; ++j)
+        Y[j] = lr0 + j < A.rows.rows ? (float)(A.rows.image_row(lr0 + j) - A.H / 2) : __builtin_nanf("");
+    // ray number: local pixel (the triangle chunks of a pixel share its count, list and bound)
+    const long slot0 = (long)lr0 * A.W + px0;
+
+    // column c of the lane has X = px0 + COLS c - W/2 (driver.c:131); the planes and boxes are in
+    // units of COLS pixels, so the sweep works with X / COLS = Xs0 + c (exact in fp32)
+    const float Xs0 = (float)(px0 - A.W / 2) * (1.0f / COLS);
+    unsigned long long on_image = 0;        // bit j RX + c: that pixel of the lane exists
+#pragma unroll
+    for (int j = 0; j < RY; ++j)
+#pragma unroll
+        for (int c = 0; c < RX; ++c)
+            on_image |= ((px0 + COLS * c < A.W) && (lr0 + j < A.rows.rows) ? 1ull : 0ull) << (j * RX + c);
 
     WaveRect rect{};
     if constexpr (CULL) {
@@ -301,7 +333,12 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
         // local rows that exist (an interleaved row part maps them anywhere)
         const int x_last = wave_x0 + COLS * R - 1 < A.W - 1 ? wave_x0 + COLS * R - 1 : A.W - 1;
         const float xa = (float)(wave_x0 - A.W / 2), xb = (float)(x_last - A.W / 2);
-        float ya = lr < A.rows.rows ? Y : INF, yb = lr < A.rows.rows ? Y : -INF;
+        float ya = INF, yb = -INF;              // (the minimum and maximum pass over a missing row's NaN)
+#pragma unroll
+        for (int j = 0; j < RY; ++j) {
+            ya = __builtin_fminf(ya, Y[j]);
+            yb = __builtin_fmaxf(yb, Y[j]);
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             ya = __builtin_fminf(ya, __shfl_xor(ya, off));

@@ -82,6 +82,18 @@ KERNEL1(k_apex8_circle, "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %9, %1\n" "v_mul
 // bounding box in x (the distance from the box's centre steps by one from pixel to pixel; a
 // three-way minimum takes two pixels), the lane's row against it in y: 99 instructions
 KERNEL1(k_raster64_box, "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %6, %9, %1\n" "v_add_f32 %3, 1.0, %2\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_add_f32 %3, 1.0, %2\n" "v_add_f32 %2, 1.0, %3\n" "v_min3_f32 %4, %4, |%3|, |%2|\n" "v_cmp_ge_f32 vcc, %7, %4\n" "v_cmp_ge_f32 vcc, %5, |%6|\n" )
+// the pixel-grid sweep's first test with a lane's 64 pixels as 8 rows x 8 columns: one interval test
+// per column (the distance steps by one: additions) and per row (subtractions), a three-way
+// minimum per two of either: 26 instructions per 64 pairs
+KERNEL1(k_raster64_block, "v_sub_f32 %2, %8, %0\n" "v_add_f32 %3, 1.0, %2\n" "v_min3_f32 %4, %4, |%2|, |%3|\n"
+        "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n"
+        "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n"
+        "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n"
+        "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n"
+        "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n"
+        "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n"
+        "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n"
+        "v_cmp_ge_f32 vcc, %7, %4\n" "v_cmp_ge_f32 vcc, %7, %6\n")
 // the any-hit sweep's first test: the u half of the bounding square, 8 rays per lane
 KERNEL1(k_apex8_strip, "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_cmp_ge_f32 vcc, %7, %4\n" )
 template <class K>
@@ -156,7 +168,8 @@ int main()
     run_mix("raster64", k_raster64, out, wgs, 195, 64);
     run_mix("apex8", k_apex8, out, wgs, 45, 8);
     run_mix("apex8_sign", k_apex8_sign, out, wgs, 41, 8);
-    run_mix("raster64_box", k_raster64_box, out, wgs, 99, 64);
+    run_mix("raster64_rowbox", k_raster64_box, out, wgs, 99, 64);
+    run_mix("raster64_box", k_raster64_block, out, wgs, 26, 64);
     run_mix("apex8_box", k_apex8_box, out, wgs, 29, 8);
     run_mix("apex8_strip", k_apex8_strip, out, wgs, 13, 8);
     run_mix("apex8_circle", k_apex8_circle, out, wgs, 37, 8);
