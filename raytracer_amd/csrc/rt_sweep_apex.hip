@@ -173,28 +173,40 @@ __device__ __forceinline__ void finish_raster(const SweepArgs& A, long slot, int
         atomicMin(reinterpret_cast<int*>(A.best_hi + slot), __float_as_int(t + terr));
 }
 
-// One triangle against the R pixels of a lane, a block of RY rows by RX columns (the columns
-// RT_RASTER_COLS pixels apart).  box = (cx, rx, cy, ry): the triangle's bounding box on the pixel
-// grid, x in units of RT_RASTER_COLS pixels (k_pack_apex).  A pixel lies in the box when its
-// column lies in the box's x extent and its row in the y extent, so the first test of the lane's
-// R pairs is one interval test per column, |Xs - cx| <= rx (Xs - cx steps by one from column to
-// column: one addition each), one per row, |Y - cy| <= ry (one subtraction each), and a
-// three-way minimum per two of either: some pixel of the block is in the box exactly when some
-// column and some row are.  A lane with a pixel inside fetches the triangle's planes from memory
-// (tri is wave-uniform) and runs the inside test on the pixels of the box.
+// One triangle against the R pixels of a lane, a lattice of RY rows by RX columns (the columns
+// RasterLane<R>::SX pixels apart, the rows SY local rows: the lanes of a wave interleave, so that
+// the pixels of a small box spread over many lanes and the rare path runs them side by side).
+// box = (cx, rx, cy, ry): the triangle's bounding box on the pixel grid, x in units of
+// RT_RASTER_COLS pixels (k_pack_apex).  A pixel lies in the box when its column lies in the box's
+// x extent and its row in the y extent, so the first test of the lane's R pairs is one interval
+// test per column, |Xs - cx| <= rx (Xs - cx steps by a constant from column to column: one
+// addition each), one per row, |Y - cy| <= ry (one subtraction each), and a three-way minimum
+// per two of either: some pixel of the lattice is in the box exactly when some column and some
+// row are.  A lane with a pixel inside fetches the triangle's planes from memory (tri is
+// wave-uniform) and runs the inside test on the pixels of the box.
+template <int R>
+struct RasterLane {
+    static constexpr int RY = rt_raster_lane_rows(R), RX = R / RY;
+    static constexpr int SY = RT_TILE_H / RY;                   // local rows between a lane's rows
+    static constexpr int SX = RT_RASTER_COLS * RY;              // pixels between a lane's columns
+    static constexpr float KX = (float)(SX / RT_RASTER_COLS);   // the same in the boxes' x unit
+    static_assert(SX * SY == 64 && SX * RX == RT_RASTER_COLS * R, "the lanes' lattices tile the wave's pixels");
+};
+
 template <int R>
 __device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4& box, int tri, float Xs0,
                                                 const float (&Y)[rt_raster_lane_rows(R)],
                                                 unsigned long long on_image, long slot0)
 {
-    constexpr int COLS = RT_RASTER_COLS;
-    constexpr int RY = rt_raster_lane_rows(R), RX = R / RY;
+    using L = RasterLane<R>;
+    constexpr int RY = L::RY, RX = L::RX;
+    constexpr float KX = L::KX;
     const float d0 = Xs0 - box.x;
     float accx = INF;
     if (RX == 1) accx = __builtin_fabsf(d0);
 #pragma unroll
     for (int c = 0; c + 1 < RX; c += 2)     // (d0 + 0.0f is not d0 to the compiler: it would keep the addition)
-        accx = min3_abs(accx, c == 0 ? d0 : d0 + (float)c, d0 + (float)(c + 1));
+        accx = min3_abs(accx, c == 0 ? d0 : d0 + KX * (float)c, d0 + KX * (float)(c + 1));
     float dy[RY];
 #pragma unroll
     for (int j = 0; j < RY; ++j) dy[j] = Y[j] - box.z;      // (a row beyond the band has Y = NaN and never passes)
@@ -203,17 +215,17 @@ __device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4
 #pragma unroll
     for (int j = 0; j + 1 < RY; j += 2) accy = min3_abs(accy, dy[j], dy[j + 1]);
     if (__builtin_expect(accx <= box.y && accy <= box.w, 0)) {
-        // the columns of the box: c with |d0 + c| <= rx, one more on either side for the rounding
+        // the columns of the box: c with |d0 + KX c| <= rx, one more on either side for the rounding
         // of these two bounds (the inside test decides about every pixel it is given)
-        int c_lo = (int)__builtin_floorf(__builtin_fmaxf(-box.y - d0, 0.0f)) - 1;
-        int c_hi = (int)__builtin_ceilf(__builtin_fminf(box.y - d0, (float)(RX - 1))) + 1;
+        int c_lo = (int)__builtin_floorf(__builtin_fmaxf((-box.y - d0) * (1.0f / KX), 0.0f)) - 1;
+        int c_hi = (int)__builtin_ceilf(__builtin_fminf((box.y - d0) * (1.0f / KX), (float)(RX - 1))) + 1;
         c_lo = c_lo < 0 ? 0 : c_lo;
         c_hi = c_hi > RX - 1 ? RX - 1 : c_hi;
 #if RT_RASTER_CHECK_INTERVAL
         {
             unsigned pass = 0;
 #pragma unroll
-            for (int k = 0; k < RX; ++k) pass |= (__builtin_fabsf(d0 + (float)k) <= box.y ? 1u : 0u) << k;
+            for (int k = 0; k < RX; ++k) pass |= (__builtin_fabsf(d0 + KX * (float)k) <= box.y ? 1u : 0u) << k;
             const unsigned inside = c_lo > c_hi ? 0u : (((2u << c_hi) - 1u) & ~((1u << c_lo) - 1u));
             if ((pass & ~inside) && A.tests) atomicAdd(A.tests, 1ull << 48);
         }
@@ -232,7 +244,8 @@ __device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4
             for (int k = 1; k < RY; ++k) Yj = j == k ? Y[k] : Yj;
             for (int c = c_lo; c <= c_hi; ++c)
                 if ((on_image >> (j * RX + c)) & 1ull)
-                    finish_raster(A, slot0 + (long)j * A.W + COLS * c, tri, P, margin, Hh, N, Xs0 + (float)c, Yj);
+                    finish_raster(A, slot0 + (long)(j * L::SY) * A.W + L::SX * c, tri, P, margin, Hh, N,
+                                  Xs0 + KX * (float)c, Yj);
         }
     }
 }
@@ -269,7 +282,7 @@ __device__ __forceinline__ void stage_boxes(const float4* __restrict__ boxes, in
 // the same either way; what changes is that most (pixel, triangle) pairs are then decided 64 R
 // at a time instead of one by one.
 template <int R, bool CULL>
-__global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const SweepArgs A)
+__global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : RT_RASTER_WAVES) k_sweep_raster(const SweepArgs A)
 {
     // (one more entry: the read-ahead of the all-pairs loop touches the one behind the second buffer)
     __shared__ float4 tile_lds[2 * RT_CULL_GROUP * RT_TILE + 1];
@@ -281,13 +294,13 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
 
     // wave = (COLS R) x (64 / COLS) pixels; workgroup = its four waves side by side ((16 R) x 16
     // pixels), two by two or stacked.  (The squarer a wave's pixels, the fewer triangles have one
-    // of them in their box: the rare path is paid per wave.)  A lane's R pixels are a block of RY
-    // rows by RX columns COLS pixels apart: RY such blocks side by side, each four lanes wide
-    // (the column phases), fill the wave's width, 16 / RY rows of blocks its height.
+    // of them in their box: the rare path is paid per wave.)  A lane's R pixels are a lattice of
+    // RY rows SY apart by RX columns SX apart, and the wave's SX x SY = 64 lanes are the
+    // lattice's phases: neighbouring pixels belong to different lanes.
     constexpr int COLS = RT_RASTER_COLS;
-    constexpr int RY = rt_raster_lane_rows(R), RX = R / RY;
+    using L = RasterLane<R>;
+    constexpr int RY = L::RY, RX = L::RX, SX = L::SX, SY = L::SY;
     static_assert(64 / COLS == RT_TILE_H, "a wave covers RT_TILE_H rows");
-    static_assert(RT_TILE_H % RY == 0 && R % RY == 0, "a lane's block divides the wave's pixels");
     // the four waves: waves_x side by side, the rest below (whichever wastes fewer pixels beyond
     // the image's right and bottom edges)
     // ... or, waves_x = 0, the wave-sized blocks of the band numbered row by row and dealt four
@@ -305,27 +318,26 @@ __global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES) k_sweep_raster(const S
         wave_x0 = txi * tile_w + (wave & (wx - 1)) * (COLS * R);
         wave_y0 = tyi * tile_h + (wave / wx) * RT_TILE_H;
     }
-    const int block = lane / COLS;                                  // 0 .. 15: which block of the wave
-    const int px0 = wave_x0 + (block % RY) * (COLS * RX) + (lane % COLS);
-    const int lr0 = wave_y0 + (block / RY) * RY;                    // first local row of the call's row set
+    const int px0 = wave_x0 + lane % SX;
+    const int lr0 = wave_y0 + lane / SX;                            // first local row of the call's row set
     // a wave that lies wholly beyond the image's right or bottom edge only helps to stage tiles
     const bool wave_on = __builtin_amdgcn_readfirstlane((wave_x0 < A.W && wave_y0 < A.rows.rows) ? 1 : 0) != 0;
     float Y[RY];                                                    // driver.c:132; NaN for a row beyond the band
 #pragma unroll
     for (int j = 0; j < RY; ++j)
-        Y[j] = lr0 + j < A.rows.rows ? (float)(A.rows.image_row(lr0 + j) - A.H / 2) : __builtin_nanf("");
+        Y[j] = lr0 + SY * j < A.rows.rows ? (float)(A.rows.image_row(lr0 + SY * j) - A.H / 2) : __builtin_nanf("");
     // ray number: local pixel (the triangle chunks of a pixel share its count, list and bound)
     const long slot0 = (long)lr0 * A.W + px0;
 
-    // column c of the lane has X = px0 + COLS c - W/2 (driver.c:131); the planes and boxes are in
-    // units of COLS pixels, so the sweep works with X / COLS = Xs0 + c (exact in fp32)
+    // column c of the lane has X = px0 + SX c - W/2 (driver.c:131); the planes and boxes are in
+    // units of COLS pixels, so the sweep works with X / COLS = Xs0 + (SX / COLS) c (exact in fp32)
     const float Xs0 = (float)(px0 - A.W / 2) * (1.0f / COLS);
     unsigned long long on_image = 0;        // bit j RX + c: that pixel of the lane exists
 #pragma unroll
     for (int j = 0; j < RY; ++j)
 #pragma unroll
         for (int c = 0; c < RX; ++c)
-            on_image |= ((px0 + COLS * c < A.W) && (lr0 + j < A.rows.rows) ? 1ull : 0ull) << (j * RX + c);
+            on_image |= ((px0 + SX * c < A.W) && (lr0 + SY * j < A.rows.rows) ? 1ull : 0ull) << (j * RX + c);
 
     WaveRect rect{};
     if constexpr (CULL) {
