@@ -66,7 +66,7 @@ constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
 // Sweeps of rays through a common point (rt_sweep_apex.hip): the eye for primary rays, a
 // light for its shadow rays.  4 float4 planes per triangle, packed per apex by k_pack_apex.
 #ifndef RT_RASTER_RPL
-#define RT_RASTER_RPL 64    // most pixels per lane of the primary (pixel-grid) sweep
+#define RT_RASTER_RPL 256   // most pixels per lane of the primary (pixel-grid) sweep
 #endif
 #define RT_RASTER_COLS 4     // pixel columns a lane's pixels are apart (a wave is COLS R x 64/COLS pixels)
 #ifndef RT_APEX_RPL
@@ -78,7 +78,7 @@ constexpr int RT_LIGHT_PLANES = RT_APEX_PLANES + 3;
 constexpr int RT_APEX_LIGHTS = 4;   // lights swept per any-hit launch (plane sets kept side by side)
 constexpr int RT_APEX_SETS = 3 * RT_APEX_LIGHTS;    // ray sets per launch: light x dominant axis
 // A lane's rpl pixels in the pixel-grid sweep are a block of this many rows (by rpl / rows columns).
-constexpr int rt_raster_lane_rows(int rpl) { return rpl >= 64 ? 8 : (rpl >= 16 ? 4 : (rpl >= 4 ? 2 : 1)); }
+constexpr int rt_raster_lane_rows(int rpl) { return rpl >= 256 ? 16 : (rpl >= 64 ? 8 : (rpl >= 16 ? 4 : (rpl >= 4 ? 2 : 1))); }
 // Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels = rows x columns): the
 // distance of the first column from the box's centre and one addition for each further column,
 // one subtraction per row, a three-way minimum per two columns and per two rows (`logic`) and

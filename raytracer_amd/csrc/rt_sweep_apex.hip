@@ -195,8 +195,8 @@ struct RasterLane {
 
 template <int R>
 __device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4& box, int tri, float Xs0,
-                                                const float (&Y)[rt_raster_lane_rows(R)],
-                                                unsigned long long on_image, long slot0)
+                                                const float (&Y)[rt_raster_lane_rows(R)], int px0, int lr0,
+                                                long slot0)
 {
     using L = RasterLane<R>;
     constexpr int RY = L::RY, RX = L::RX;
@@ -243,7 +243,7 @@ __device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4
 #pragma unroll
             for (int k = 1; k < RY; ++k) Yj = j == k ? Y[k] : Yj;
             for (int c = c_lo; c <= c_hi; ++c)
-                if ((on_image >> (j * RX + c)) & 1ull)
+                if (px0 + L::SX * c < A.W && lr0 + L::SY * j < A.rows.rows)      // the pixel exists
                     finish_raster(A, slot0 + (long)(j * L::SY) * A.W + L::SX * c, tri, P, margin, Hh, N,
                                   Xs0 + KX * (float)c, Yj);
         }
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : RT_RASTER_WAVES) 
     // lattice's phases: neighbouring pixels belong to different lanes.
     constexpr int COLS = RT_RASTER_COLS;
     using L = RasterLane<R>;
-    constexpr int RY = L::RY, RX = L::RX, SX = L::SX, SY = L::SY;
+    constexpr int RY = L::RY, SX = L::SX, SY = L::SY;
     static_assert(64 / COLS == RT_TILE_H, "a wave covers RT_TILE_H rows");
     // the four waves: waves_x side by side, the rest below (whichever wastes fewer pixels beyond
     // the image's right and bottom edges)
@@ -332,13 +332,6 @@ __global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : RT_RASTER_WAVES) 
     // column c of the lane has X = px0 + SX c - W/2 (driver.c:131); the planes and boxes are in
     // units of COLS pixels, so the sweep works with X / COLS = Xs0 + (SX / COLS) c (exact in fp32)
     const float Xs0 = (float)(px0 - A.W / 2) * (1.0f / COLS);
-    unsigned long long on_image = 0;        // bit j RX + c: that pixel of the lane exists
-#pragma unroll
-    for (int j = 0; j < RY; ++j)
-#pragma unroll
-        for (int c = 0; c < RX; ++c)
-            on_image |= ((px0 + SX * c < A.W) && (lr0 + SY * j < A.rows.rows) ? 1ull : 0ull) << (j * RX + c);
-
     WaveRect rect{};
     if constexpr (CULL) {
         // columns wave_x0 .. the wave's last one on the image; rows: the image rows of the wave's
@@ -389,7 +382,7 @@ __global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : RT_RASTER_WAVES) 
                 while (keep) {
                     const int j = h * 64 + __builtin_ctzll(keep);
                     keep &= keep - 1;
-                    raster_triangle<R>(A, base[j], tri0 + j, Xs0, Y, on_image, slot0);
+                    raster_triangle<R>(A, base[j], tri0 + j, Xs0, Y, px0, lr0, slot0);
                 }
             }
         } else {
@@ -408,7 +401,7 @@ __global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : RT_RASTER_WAVES) 
                     for (int k = 0; k < kRasterUnroll; ++k) {
                         const float4 box = next;
                         next = lds_read_float4(box_at + 16u * (unsigned)(k + 1));
-                        raster_triangle<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, Y, on_image, slot0);
+                        raster_triangle<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, Y, px0, lr0, slot0);
                     }
                     box_at += 16u * kRasterUnroll;
                 }
@@ -1056,7 +1049,8 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
         int fr = 0, fc = 0, fw = 0;
         const int n = sscanf(force, "%d,%d,%d", &fr, &fc, &fw);
         if (n >= 2 && fc >= 1 && fc <= (tiles < 1 ? 1 : tiles) &&
-            (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == 16 || fr == 32 || fr == 64) && fr <= RT_RASTER_RPL) {
+            (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == 16 || fr == 32 || fr == 64 || fr == 128 || fr == 256) &&
+            fr <= RT_RASTER_RPL) {
             *pixels_per_lane = fr;
             *chunks = fc;
             *waves_x = (n == 3 && (fw == 0 || fw == 1 || fw == 2 || fw == 4)) ? fw : best_layout(fr);
@@ -1132,6 +1126,12 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
 #endif
 #if RT_RASTER_RPL >= 64
         RT_RASTER_CASE(64)
+#endif
+#if RT_RASTER_RPL >= 128
+        RT_RASTER_CASE(128)
+#endif
+#if RT_RASTER_RPL >= 256
+        RT_RASTER_CASE(256)
 #endif
     }
 #undef RT_RASTER_CASE

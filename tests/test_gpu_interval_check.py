@@ -1,7 +1,7 @@
-"""The primary sweep's rare path finds the pixels of a lane that lie in a triangle's bounding
-box as an interval of pixel numbers (two subtractions) instead of evaluating every pixel of the
+"""The primary sweep's rare path finds the columns of a lane that lie in a triangle's bounding
+box as an interval of column numbers (two subtractions) instead of evaluating every column of the
 lane again.  A checking build of the same sources (raytracer_amd/librt_amd_check.so,
--DRT_RASTER_CHECK_INTERVAL=1) does both and counts the pixels the hot loop's own test passes
+-DRT_RASTER_CHECK_INTERVAL=1) does both and counts the columns the hot loop's own test passes
 that lie outside the interval; there must be none, on hard scenes and for every lane width."""
 import os
 import re
@@ -33,7 +33,7 @@ for mesh in meshes:
 """
 
 
-@pytest.mark.parametrize("shape", [None, "64,4,1", "32,4,2", "16,3,4", "8,2,1", "32,5,0"])
+@pytest.mark.parametrize("shape", [None, "256,3,0", "128,4,1", "64,4,1", "32,4,2", "16,3,4", "8,2,1", "32,5,0"])
 def test_no_pass_outside_the_interval(shape):
     if not os.path.exists(CHECK_LIB):
         pytest.fail("raytracer_amd/librt_amd_check.so is missing: run __graft_entry__.build()")
