@@ -686,7 +686,9 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
 #endif
     a.tri_begin = 0; a.tri_end = sc->num_tris_padded;
-    const uint64_t tests = (uint64_t)rt_raster_pairs(W, rows.rows, rpl, sc->num_tris_padded);
+    // pairs of the band's own pixels (the lanes of a wave that reaches beyond the image's edge
+    // execute their tests too; those are not counted)
+    const uint64_t tests = (uint64_t)npix * (uint64_t)sc->num_tris_padded;
     g.last_raster_rpl.store(rpl, std::memory_order_relaxed);
     g.last_raster_chunks.store(chunks, std::memory_order_relaxed);
     RT_TRY(timed_sweep([&] { return rt_launch_sweep_raster(a, st); }, false, tests, nullptr));

@@ -1067,8 +1067,16 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
         const RasterMix m = rt_raster_mix(r), h = rt_raster_mix(r / 2);
         const double cost = (double)(m.fma + m.add + m.logic + m.compare) / r * swept(r);
         const double cost_half = (double)(h.fma + h.add + h.logic + h.compare) / (r / 2) * swept(r / 2);
-        // ... unless the wider lanes leave too few workgroups for eight rounds of the machine
-        const bool enough = rt_raster_tiles(W, rows, r, best_layout(r)) * max_chunks >= 8 * slots;
+        // ... unless the wider lanes leave too few workgroups for four rounds of the machine with
+        // chunks of at least two tiles (a workgroup of wide lanes has more to set up, and a
+        // one-tile chunk does not repay it: the 6 k-triangle mesh at 4K sweeps in 0.6 ms with 128
+        // pixels per lane and in 1.2 ms with 256)
+        const long long_chunks = tiles / 2 < 1 ? 1 : (tiles / 2 < max_chunks ? tiles / 2 : max_chunks);
+        bool enough = rt_raster_tiles(W, rows, r, best_layout(r)) * long_chunks >= 4 * slots;
+        // (the widest lanes only for large meshes: on the 69 k- and 100 k-triangle closed meshes at
+        // 4K, whose triangles are larger on the screen, a 1024-pixel wave enters the rare path
+        // often enough for 128 pixels per lane to win, 3.7 against 4.3 ms and 4.4 against 4.6)
+        if (r > 128 && tiles < 1024) enough = false;
         if (cost <= cost_half && enough) break;
         r /= 2;
     }

@@ -94,6 +94,9 @@ KERNEL1(k_raster64_block, "v_sub_f32 %2, %8, %0\n" "v_add_f32 %3, 1.0, %2\n" "v_
         "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n"
         "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n"
         "v_cmp_ge_f32 vcc, %7, %4\n" "v_cmp_ge_f32 vcc, %7, %6\n")
+// ... as 8 rows x 16 columns (128 pixels, 38 instructions) and 16 x 16 (256 pixels, 50 instructions)
+KERNEL1(k_raster128_block, "v_sub_f32 %2, %8, %0\n" "v_add_f32 %3, 1.0, %2\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_cmp_ge_f32 vcc, %7, %4\n" "v_cmp_ge_f32 vcc, %7, %6\n")
+KERNEL1(k_raster256_block, "v_sub_f32 %2, %8, %0\n" "v_add_f32 %3, 1.0, %2\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_cmp_ge_f32 vcc, %7, %4\n" "v_cmp_ge_f32 vcc, %7, %6\n")
 // the any-hit sweep's first test: the u half of the bounding square, 8 rays per lane
 KERNEL1(k_apex8_strip, "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_cmp_ge_f32 vcc, %7, %4\n" )
 template <class K>
@@ -170,6 +173,8 @@ int main()
     run_mix("apex8_sign", k_apex8_sign, out, wgs, 41, 8);
     run_mix("raster64_rowbox", k_raster64_box, out, wgs, 99, 64);
     run_mix("raster64_box", k_raster64_block, out, wgs, 26, 64);
+    run_mix("raster128_box", k_raster128_block, out, wgs, 38, 128);
+    run_mix("raster256_box", k_raster256_block, out, wgs, 50, 256);
     run_mix("apex8_box", k_apex8_box, out, wgs, 29, 8);
     run_mix("apex8_strip", k_apex8_strip, out, wgs, 13, 8);
     run_mix("apex8_circle", k_apex8_circle, out, wgs, 37, 8);
