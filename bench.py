@@ -372,10 +372,14 @@ def main() -> None:
             # ray-triangle pair (an addition = 1; rocprof SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 agree,
             # see profiles/) against the fp32 vector peak.  What actually bounds the loop is
             # instruction issue (one VALU instruction per SIMD every two cycles, whatever it
-            # computes): per pair it steps the pixel's distance from the centre of the triangle's
-            # bounding box by one addition and collects two of those in a three-way minimum, so
-            # `valu_issue` is the figure that says how close the kernel is to the machine's limit,
-            # and the stated target of half the fp32 flop peak is not met by construction.
+            # computes): a lane's pixels are a lattice of rows and columns, and per triangle it
+            # steps each column's and each row's distance from the centre of the triangle's
+            # bounding box by one addition or subtraction and collects two of those in a three-way
+            # minimum (a pixel is in the box when its column and its row are), so `valu_issue` is
+            # the figure that says how close the kernel is to the machine's limit, and the stated
+            # target of half the fp32 flop peak is not met by construction.  The pairs are those
+            # of the image's own pixels: the lanes of a wave that reaches beyond the right edge
+            # execute their tests too, uncounted.
             "roofline": {
                 "bound": "valu-fp32", "kernel": f"k_sweep_raster<{ppl.value}, false> (primary rays, closest hit, all pairs)",
                 "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

@@ -29,15 +29,16 @@
 //                   trace_shadow_rays in rt_api.hip).
 //   k_sweep_raster  closest hit for the pixel grid.  D = (X, Y, ez) with integer X, Y and a
 //                   constant ez that k_pack_apex folds into the z components.  Each lane owns
-//                   RT_RASTER_RPL pixels of one row, RT_RASTER_COLS columns apart.  First test of
-//                   a pair: the pixel against the bounding box of the triangle's projection
-//                   onto the image plane (k_pack_apex writes one per triangle, allowances
-//                   included): the distance from the box's centre steps by one from pixel to
-//                   pixel of the lane -- one addition per pixel and a three-way minimum per two
-//                   pixels, 99 VALU instructions per 64 pairs.  Every (pixel, triangle) pair is
-//                   still tested individually.  Primary rays leave P, which fixes the sign of
-//                   det for a hit, so k_pack_apex orients every triangle (sign layout) for
-//                   the rare path's inside test.
+//                   up to RT_RASTER_RPL pixels, a lattice of rows and columns of the image.
+//                   First test of a pair: the pixel against the bounding box of the
+//                   triangle's projection onto the image plane (k_pack_apex writes one per
+//                   triangle, allowances included).  A pixel is in the box when its column is
+//                   in the box's x extent and its row in the y extent, so a lane evaluates one
+//                   interval test per column and per row of its lattice -- 50 VALU instructions
+//                   per 256 pairs -- and every pixel's verdict is the one it would get on its
+//                   own.  Primary rays leave P, which fixes the sign of det for a hit, so
+//                   k_pack_apex orients every triangle (sign layout) for the rare path's
+//                   inside test.
 //
 // The sweeps stream what their first test reads through LDS in tiles of RT_TILE triangles,
 // double-buffered by LDS-DMA loads and read at wave-uniform addresses (broadcast, no bank
