@@ -337,7 +337,9 @@ def main() -> None:
         # the any-hit sweeps of the shadow rays: a third of the frame
         sh_ms, sh_tests = prof.shadow_ms, float(prof.shadow_tests)
         sh_rate = sh_tests / (sh_ms * 1e-3) if sh_ms > 0 else 0.0
-        sh_instr = 13.0 / 8.0                     # hot loop: 13 VALU instructions per 8 pairs (u half of the bounding-square test)
+        # hot loop of the widest any-hit kernel (u half of the bounding-square test): a subtraction per
+        # ray, a three-way minimum per two, one compare per triangle (25 VALU instructions per 16 pairs)
+        sh_instr = (spl.value + spl.value // 2 + 1) / spl.value
         rp_sh = rocprof_avg_ms(args.workload, f"k_sweep_apex<{spl.value}, false>") if world == 1 else None
         res = {
             "metric": "Mrays/s and ray-tri tests/s (% fp32 peak) at 1/2/4/8 MI355X vs host-CPU ref",

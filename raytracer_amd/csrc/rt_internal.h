@@ -70,7 +70,7 @@ constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
 #endif
 #define RT_RASTER_COLS 4     // pixel columns a lane's pixels are apart (a wave is COLS R x 64/COLS pixels)
 #ifndef RT_APEX_RPL
-#define RT_APEX_RPL 8       // rays per lane of the any-hit apex sweep
+#define RT_APEX_RPL 16      // most rays per lane of the any-hit apex sweep (8, 4, 2, 1 for smaller batches)
 #endif
 constexpr int RT_APEX_PLANES = 4;
 // a light's plane set: the four apex planes and the bounding squares for the three dominant axes
@@ -99,7 +99,7 @@ constexpr double rt_raster_flop_per_pair(int rpl)
     return (2.0 * rt_raster_mix(rpl).fma + rt_raster_mix(rpl).add) / rpl;
 }
 constexpr double RT_APEX_FLOP_PER_PAIR = 1.0;
-constexpr double RT_APEX_INSTR_PER_PAIR = 13.0 / 8.0;
+constexpr double RT_APEX_INSTR_PER_PAIR = 25.0 / 16.0;     // 16 rays per lane: 16 subtractions, 8 minima, 1 compare
 
 // per-ray candidate counter written by the sweep: low bits = candidates pushed, plus
 constexpr int RT_CNT_OCCLUDED = 0x40000000;   // any-hit: a certain hit was found

@@ -49,6 +49,10 @@
 #ifndef RT_APEX8_WAVES
 #define RT_APEX8_WAVES 6    // waves per SIMD the 8-rays-per-lane any-hit kernel must fit
 #endif
+#ifndef RT_APEX16_WAVES
+#define RT_APEX16_WAVES 5   // ... and the 16-rays-per-lane one (96 registers; measured: six waves spill
+                            // into the hot loop, four leave LDS latency exposed)
+#endif
 #ifndef RT_APEX_POLL
 #define RT_APEX_POLL 16     // tiles between looks at the flags other chunks may have set (power of two)
 #endif
@@ -794,7 +798,8 @@ __device__ __forceinline__ void apex_tiles_culled(const SweepArgs& A, float4 (*t
 // lists of light l start l * light_ray_stride rays into their arrays, its planes
 // l * light_plane_stride float4 into theirs.
 template <int R, bool CULL>
-__global__ void __launch_bounds__(RT_WG, R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES) k_sweep_apex(SweepArgs A)
+__global__ void __launch_bounds__(RT_WG, R >= 16 ? RT_APEX16_WAVES : (R >= 8 ? RT_APEX8_WAVES : RT_MIN_WAVES))
+k_sweep_apex(SweepArgs A)
 {
     // all pairs: two buffers of one tile's five planes; tile culling: two of a group's squares
     constexpr int kTileFloat4 = CULL ? RT_CULL_GROUP * RT_TILE : (RT_APEX_PLANES + 1) * RT_TILE;
@@ -1166,10 +1171,16 @@ static int apex_max_chunks(int tiles, int mesh_tiles)
 // pairs with more rays per lane: below 4 the loop is bound by LDS bandwidth.  So the machine is
 // filled with triangle chunks first, and rays per lane are given up only when the chunks do
 // not suffice: 8 (at 4 waves per SIMD) wants six workgroups per CU, the others two to three.
-static int apex_rays_per_lane(long n, int max_chunks)
+static int apex_rays_per_lane(long n, int max_chunks, bool long_late_range)
 {
     int r = RT_APEX_RPL;
-    if (r >= 8 && (n / (RT_WG * r)) * max_chunks < 6L * rt_device_cus()) r = 4;
+    // (16 rays per lane pay where a million rays and more sweep a long range of triangles after
+    // the occluded ones have gone -- the late ranges of the 1 M-triangle 4K frame: 60.3 ms of
+    // shadow sweeps against 62.8 -- and cost a few percent everywhere else measured, where rays
+    // still retire and a wave of 1024 keeps going for its last one: first ranges, the 70-100 k
+    // closed meshes, the 6 k-triangle one, an eighth of the frame)
+    if (r > 8 && !(long_late_range && n >= 1000000)) r = 8;
+    while (r >= 8 && (n / (RT_WG * r)) * max_chunks < 6L * rt_device_cus()) r /= 2;
     while (r > 1 && r <= 4 && 2 * ((n + RT_WG * r - 1) / (RT_WG * r)) * max_chunks < 5L * rt_device_cus()) r /= 2;
     return r;
 }
@@ -1199,13 +1210,14 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
     const int max_chunks = apex_max_chunks(tiles, a.num_tris_padded / RT_TILE);
     // shape from the host's estimate of the live rays where it has one (the bound may be a range stale)
     const long shape_rays = a.est_rays > 0 ? a.est_rays : (a.total_rays > 0 ? a.total_rays : (long)a.n_rays * a.lights);
-    int r = apex_rays_per_lane(shape_rays, max_chunks);
+    int r = apex_rays_per_lane(shape_rays, max_chunks, a.resume && 8 * tiles >= a.num_tris_padded / RT_TILE);
+    if (a.cull && r > 8) r = 8;     // (tile culling tests a wave's whole bundle first: the narrower, the better)
     int forced_chunks = 0;
     // RT_AMD_APEX_FORCE="<rays per lane>,<chunks>": tests run every kernel shape on small inputs
     if (const char* force = getenv("RT_AMD_APEX_FORCE")) {
         int fr = 0, fc = 0;
         if (sscanf(force, "%d,%d", &fr, &fc) == 2 && fc >= 1 &&
-            (fr == 1 || fr == 2 || fr == 4 || fr == RT_APEX_RPL)) {
+            (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == 16) && fr <= RT_APEX_RPL) {
             r = fr;
             forced_chunks = fc > tiles ? (tiles < 1 ? 1 : tiles) : fc;
         }
@@ -1222,8 +1234,11 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
         RT_APEX_CASE(1)
         RT_APEX_CASE(2)
         RT_APEX_CASE(4)
-#if RT_APEX_RPL > 4
-        RT_APEX_CASE(RT_APEX_RPL)
+#if RT_APEX_RPL >= 8
+        RT_APEX_CASE(8)
+#endif
+#if RT_APEX_RPL >= 16
+        RT_APEX_CASE(16)
 #endif
     }
 #undef RT_APEX_CASE

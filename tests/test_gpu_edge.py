@@ -478,7 +478,7 @@ def test_every_shape_of_the_pixel_grid_sweep(shape, W, H, monkeypatch):
     sc.close()
 
 
-@pytest.mark.parametrize("shape", ["8,1", "8,4", "4,3", "2,2", "1,7"])
+@pytest.mark.parametrize("shape", ["16,1", "16,3", "8,1", "8,4", "4,3", "2,2", "1,7"])
 def test_every_shape_of_the_any_hit_sweep(shape, monkeypatch):
     """Same for the shadow rays' sweep: rays per lane and triangle chunks that share a ray's
     candidate list through atomics (more chunks than a few-tile range can feed included)."""

@@ -99,6 +99,8 @@ KERNEL1(k_raster128_block, "v_sub_f32 %2, %8, %0\n" "v_add_f32 %3, 1.0, %2\n" "v
 KERNEL1(k_raster256_block, "v_sub_f32 %2, %8, %0\n" "v_add_f32 %3, 1.0, %2\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_add_f32 %3, 2.0, %2\n" "v_add_f32 %5, 4.0, %2\n" "v_min3_f32 %4, %4, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_sub_f32 %3, %9, %1\n" "v_sub_f32 %5, %8, %1\n" "v_min3_f32 %6, %6, |%3|, |%5|\n" "v_cmp_ge_f32 vcc, %7, %4\n" "v_cmp_ge_f32 vcc, %7, %6\n")
 // the any-hit sweep's first test: the u half of the bounding square, 8 rays per lane
 KERNEL1(k_apex8_strip, "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_cmp_ge_f32 vcc, %7, %4\n" )
+// ... and 16 rays per lane
+KERNEL1(k_apex16_strip, "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_sub_f32 %2, %8, %0\n" "v_sub_f32 %3, %8, %1\n" "v_min3_f32 %4, %4, |%2|, |%3|\n" "v_cmp_ge_f32 vcc, %7, %4\n" )
 template <class K>
 void run_mix(const char* name, K k, float* out, int wgs, int instrs, int pairs)
 {
@@ -177,6 +179,7 @@ int main()
     run_mix("raster256_box", k_raster256_block, out, wgs, 50, 256);
     run_mix("apex8_box", k_apex8_box, out, wgs, 29, 8);
     run_mix("apex8_strip", k_apex8_strip, out, wgs, 13, 8);
+    run_mix("apex16_strip", k_apex16_strip, out, wgs, 25, 16);
     run_mix("apex8_circle", k_apex8_circle, out, wgs, 37, 8);
     (void)hipFree(out);
     return 0;
