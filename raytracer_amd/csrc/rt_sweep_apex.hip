@@ -1173,13 +1173,14 @@ static int apex_max_chunks(int tiles, int mesh_tiles)
 // not suffice: 8 (at 4 waves per SIMD) wants six workgroups per CU, the others two to three.
 static int apex_rays_per_lane(long n, int max_chunks, bool long_late_range)
 {
+    static const long kApex16MinRays = getenv("RT_AMD_APEX16_MIN_RAYS") ? atol(getenv("RT_AMD_APEX16_MIN_RAYS")) : 1000000;
     int r = RT_APEX_RPL;
     // (16 rays per lane pay where a million rays and more sweep a long range of triangles after
     // the occluded ones have gone -- the late ranges of the 1 M-triangle 4K frame: 60.3 ms of
     // shadow sweeps against 62.8 -- and cost a few percent everywhere else measured, where rays
     // still retire and a wave of 1024 keeps going for its last one: first ranges, the 70-100 k
     // closed meshes, the 6 k-triangle one, an eighth of the frame)
-    if (r > 8 && !(long_late_range && n >= 1000000)) r = 8;
+    if (r > 8 && !(long_late_range && n >= kApex16MinRays)) r = 8;
     while (r >= 8 && (n / (RT_WG * r)) * max_chunks < 6L * rt_device_cus()) r /= 2;
     while (r > 1 && r <= 4 && 2 * ((n + RT_WG * r - 1) / (RT_WG * r)) * max_chunks < 5L * rt_device_cus()) r /= 2;
     return r;
