@@ -717,9 +717,10 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
         // registers and copy to a vector register before every read (one VALU instruction per
         // triangle beside the loop's 13).  Held in a vector register the compiler cannot see
         // through, the address advances once per kApexUnroll triangles and the reads use
-        // immediate offsets.  Reads are issued one triangle ahead by hand; the last one of a
-        // tile reads the entry behind the plane (the next buffer's first, or the padding behind
-        // the tile buffers) and is not used.
+        // immediate offsets.  Reads are issued one triangle ahead by hand (two ahead was
+        // measured: no gain, more spills); the last one of a tile reads the entry behind the
+        // plane (the next buffer's first, or the padding behind the tile buffers) and is not
+        // used.
         unsigned sq_at = lds_address(tile[buf][RT_APEX_PLANES]);
         asm volatile("" : "+v"(sq_at));
         float4 next = lds_read_float4(sq_at);
@@ -734,6 +735,9 @@ __device__ __forceinline__ void apex_tiles(const SweepArgs& A, float4 (*tile)[RT
                     Hh = base[j + 2 * RT_TILE];
                     N = base[j + 3 * RT_TILE];
                 });
+                // (the record's unused fourth component stays allocated until here: its register,
+                // reused as a temporary, would have to wait for the read-ahead to land first)
+                asm volatile("" : : "v"(sq.w));
             }
             sq_at += 16u * kApexUnroll;
         }
