@@ -117,7 +117,7 @@ def mix_alone(name: str, tests_per_s: float) -> dict:
     return {}
 
 
-ROCPROF_DIR = "profiles/r02f_bench_soup1m_4k"     # tools/profile_bench.sh over this program's default run
+ROCPROF_DIR = "profiles/r02g_bench_soup1m_4k"     # tools/profile_bench.sh over this program's default run
 
 
 def rocprof_avg_ms(workload: str, kernel_prefix: str) -> dict | None:
