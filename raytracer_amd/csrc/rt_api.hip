@@ -797,9 +797,12 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
         RT_TRY(take_counts(slot_next));
         ++slot_next;
     }
-    // ranges grow by 2x (4x was measured for the short sweeps of an eighth of a frame: most parts
-    // gain a millisecond, the slowest one and every quarter lose one to the extra tests)
-    const double growth = growth_env > 1.0 ? growth_env : 2.0;
+    // ranges grow by 2x; by 3x for sweeps of fewer rays than RT_AMD_RANGE_GROWTH3_RAYS (their launches
+    // are too short to fill the machine, and four of them cost less than six: an eighth of the
+    // 1 M-triangle 4K frame takes 15.7 instead of 16.0 ms; 4x was measured too: most parts gain as
+    // much, the slowest one and every quarter lose to the extra tests)
+    static const long growth3_rays = getenv("RT_AMD_RANGE_GROWTH3_RAYS") ? atol(getenv("RT_AMD_RANGE_GROWTH3_RAYS")) : 400000;
+    const double growth = growth_env > 1.0 ? growth_env : (total < growth3_rays ? 3.0 : 2.0);
     // a sweep of a few milliseconds is not worth the compaction round trips
     // (RT_AMD_RANGE_MIN_WORK, read at every call: tests set it to 0 to run ranges on small inputs)
     const char* min_work_env = getenv("RT_AMD_RANGE_MIN_WORK");
