@@ -1027,8 +1027,8 @@ int rt_device_cus()
 // triangle range into chunks that run as separate workgroups makes the rounds shorter and fills
 // small bands.  The chunks of a pixel share its candidate list and closest-hit bound (atomics in
 // the rare path), so their number costs neither memory nor pruning: about 24 rounds of
-// workgroups, 61 chunks for a 3840x2160 frame of a million triangles, some 480 for an eighth of
-// it.  A chunk may be as short as one tile (measured: a 6 k-triangle mesh at 3840x2160 sweeps in
+// workgroups, 228 chunks for a 3840x2160 frame of a million triangles at 256 pixels per lane, the
+// cap of RT_RASTER_MAX_CHUNKS for an eighth of it.  A chunk may be as short as one tile (measured: a 6 k-triangle mesh at 3840x2160 sweeps in
 // 2.7 ms with 49 one-tile chunks, 3.3 ms with 6 chunks of 8); a mesh too small to fill the machine
 // even so gives up pixels per lane instead.  RT_AMD_RASTER_FORCE="<pixels per lane>,<chunks>[,<waves side by
 // side, 0 = dealt row by row>]" overrides the choice (read at every call: tests use it to run
