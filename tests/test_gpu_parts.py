@@ -52,3 +52,32 @@ def test_part_of_a_sub_range_and_primary_only():
                  "rt_trace_primary_part")
     assert np.array_equal(hit.cpu().numpy(), hit_all.cpu().numpy()[rows])
     sc.close()
+
+
+@pytest.mark.parametrize("kind,tris,parts", [("soup", 1_000_000, 8), ("soup", 1_000_000, 3), ("torus", 100_000, 8),
+                                             ("sphere", 69_451, 4)])
+def test_parts_of_the_4k_frames_equal_the_whole(kind, tris, parts):
+    """BASELINE configurations 4, 2-class and 3 at full size, as several GPUs would render them:
+    every interleaved part (its own launch shapes: up to 1024 triangle chunks in the primary
+    sweep, 8 rays per lane and ranges that grow by 3x in the any-hit sweeps) gives bit for bit the
+    rows of the whole-frame call (for the soup: 256 pixels per lane, 16-ray any-hit launches,
+    ranges that grow by 2x)."""
+    W, H = 3840, 2160
+    mesh = {"soup": lambda: scenes.triangle_soup(tris, seed=12345), "torus": lambda: scenes.torus(tris),
+            "sphere": lambda: scenes.sphere(tris)}[kind]()
+    fr = kernel.driver_frame(0)
+    sc = kernel.Scene(mesh)
+    sc.transform(kernel.frame_matrix(fr, "obmat"))
+    want = ("hit", "rgb8", "argb")
+    whole = {k: v.cpu().numpy() for k, v in sc.render_rows(fr, W, H, TAN_HALF, want=want).items()}
+    assert (whole["hit"] >= 0).mean() > 0.1
+    covered = np.zeros(H, dtype=bool)
+    for p in range(parts):
+        rs = kernel.rows_part(H, parts, p)
+        rows = kernel.rows_image_rows(rs)
+        covered[rows] = True
+        got = sc.render_rows(fr, W, H, TAN_HALF, rows_set=rs, want=want)
+        for k in want:
+            assert np.array_equal(got[k].cpu().numpy(), whole[k][rows]), (k, p)
+    assert covered.all()
+    sc.close()
