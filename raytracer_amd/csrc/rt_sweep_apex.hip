@@ -200,8 +200,8 @@ struct RasterLane {
 
 template <int R>
 __device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4& box, int tri, float Xs0,
-                                                const float (&Y)[rt_raster_lane_rows(R)], int px0, int lr0,
-                                                long slot0)
+                                                const float (&Y)[rt_raster_lane_rows(R)], const float* y_of_row,
+                                                int px0, int lr0, long slot0)
 {
     using L = RasterLane<R>;
     constexpr int RY = L::RY, RX = L::RX;
@@ -244,9 +244,9 @@ __device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4
         while (rows_in) {
             const int j = __builtin_ctz(rows_in);
             rows_in &= rows_in - 1;
-            float Yj = Y[0];
-#pragma unroll
-            for (int k = 1; k < RY; ++k) Yj = j == k ? Y[k] : Yj;
+            // (Y[j] for a j that differs from lane to lane: one LDS read from the wave's table of
+            // its rows instead of a chain of RY selects)
+            const float Yj = y_of_row[L::SY * j];
             for (int c = c_lo; c <= c_hi; ++c)
                 if (px0 + L::SX * c < A.W && lr0 + L::SY * j < A.rows.rows)      // the pixel exists
                     finish_raster(A, slot0 + (long)(j * L::SY) * A.W + L::SX * c, tri, P, margin, Hh, N,
@@ -331,6 +331,12 @@ __global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : RT_RASTER_WAVES) 
 #pragma unroll
     for (int j = 0; j < RY; ++j)
         Y[j] = lr0 + SY * j < A.rows.rows ? (float)(A.rows.image_row(lr0 + SY * j) - A.H / 2) : __builtin_nanf("");
+    // the same per local row of the wave, in LDS, for the rare path (which indexes it by a row
+    // number of its own in every lane): the lanes of a wave that share a row write the same value
+    __shared__ float row_y[RT_WG / 64][RT_TILE_H];
+#pragma unroll
+    for (int j = 0; j < RY; ++j) row_y[wave][lane / SX + SY * j] = Y[j];
+    const float* y_of_row = &row_y[wave][lane / SX];
     // ray number: local pixel (the triangle chunks of a pixel share its count, list and bound)
     const long slot0 = (long)lr0 * A.W + px0;
 
@@ -387,7 +393,7 @@ __global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : RT_RASTER_WAVES) 
                 while (keep) {
                     const int j = h * 64 + __builtin_ctzll(keep);
                     keep &= keep - 1;
-                    raster_triangle<R>(A, base[j], tri0 + j, Xs0, Y, px0, lr0, slot0);
+                    raster_triangle<R>(A, base[j], tri0 + j, Xs0, Y, y_of_row, px0, lr0, slot0);
                 }
             }
         } else {
@@ -406,7 +412,7 @@ __global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : RT_RASTER_WAVES) 
                     for (int k = 0; k < kRasterUnroll; ++k) {
                         const float4 box = next;
                         next = lds_read_float4(box_at + 16u * (unsigned)(k + 1));
-                        raster_triangle<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, Y, px0, lr0, slot0);
+                        raster_triangle<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, Y, y_of_row, px0, lr0, slot0);
                     }
                     box_at += 16u * kRasterUnroll;
                 }
