@@ -247,8 +247,12 @@ __device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4
             // (Y[j] for a j that differs from lane to lane: one LDS read from the wave's table of
             // its rows instead of a chain of RY selects)
             const float Yj = y_of_row[L::SY * j];
+            // (the column's own first test, the hot loop's expression: c_lo and c_hi carry a column
+            // of slack on either side, which for a box narrower than the lattice's pitch are two
+            // of three; a pixel outside the box cannot be hit and would only be rejected later)
             for (int c = c_lo; c <= c_hi; ++c)
-                if (px0 + L::SX * c < A.W && lr0 + L::SY * j < A.rows.rows)      // the pixel exists
+                if (__builtin_fabsf(d0 + KX * (float)c) <= box.y &&
+                    px0 + L::SX * c < A.W && lr0 + L::SY * j < A.rows.rows)      // ... and the pixel exists
                     finish_raster(A, slot0 + (long)(j * L::SY) * A.W + L::SX * c, tri, P, margin, Hh, N,
                                   Xs0 + KX * (float)c, Yj);
         }
