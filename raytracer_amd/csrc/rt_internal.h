@@ -66,7 +66,7 @@ constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
 // Sweeps of rays through a common point (rt_sweep_apex.hip): the eye for primary rays, a
 // light for its shadow rays.  4 float4 planes per triangle, packed per apex by k_pack_apex.
 #ifndef RT_RASTER_RPL
-#define RT_RASTER_RPL 256   // most pixels per lane of the primary (pixel-grid) sweep
+#define RT_RASTER_RPL 1024  // most pixels per lane of the primary (pixel-grid) sweep
 #endif
 #define RT_RASTER_COLS 4     // pixel columns a lane's pixels are apart (a wave is COLS R x 64/COLS pixels)
 #ifndef RT_APEX_RPL

@@ -228,10 +228,11 @@ __device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4
         c_hi = c_hi > RX - 1 ? RX - 1 : c_hi;
 #if RT_RASTER_CHECK_INTERVAL
         {
-            unsigned pass = 0;
+            unsigned long long pass = 0;
 #pragma unroll
-            for (int k = 0; k < RX; ++k) pass |= (__builtin_fabsf(d0 + KX * (float)k) <= box.y ? 1u : 0u) << k;
-            const unsigned inside = c_lo > c_hi ? 0u : (((2u << c_hi) - 1u) & ~((1u << c_lo) - 1u));
+            for (int k = 0; k < RX; ++k) pass |= (__builtin_fabsf(d0 + KX * (float)k) <= box.y ? 1ull : 0ull) << k;
+            const unsigned long long inside =
+                c_lo > c_hi ? 0ull : (((c_hi >= 63 ? 0ull : (2ull << c_hi)) - 1ull) & ~((1ull << c_lo) - 1ull));
             if ((pass & ~inside) && A.tests) atomicAdd(A.tests, 1ull << 48);
         }
 #endif
@@ -1069,7 +1070,8 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
         int fr = 0, fc = 0, fw = 0;
         const int n = sscanf(force, "%d,%d,%d", &fr, &fc, &fw);
         if (n >= 2 && fc >= 1 && fc <= (tiles < 1 ? 1 : tiles) &&
-            (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == 16 || fr == 32 || fr == 64 || fr == 128 || fr == 256) &&
+            (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == 16 || fr == 32 || fr == 64 || fr == 128 || fr == 256 ||
+             fr == 512 || fr == 1024) &&
             fr <= RT_RASTER_RPL) {
             *pixels_per_lane = fr;
             *chunks = fc;
@@ -1080,6 +1082,15 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     // (with tile culling a wave's pixel rectangle should not be too wide: the narrower, the fewer
     // triangles survive its test; 32 pixels per lane measured best on a 1 M-triangle 4K frame)
     int r = rt_tile_culling() && RT_RASTER_RPL > 32 ? 32 : RT_RASTER_RPL;
+    // The wider a wave's pixels (a lane of 1024 pixels has 64 columns of 16 rows: the wave is
+    // 4096 pixels wide), the fewer instructions a pair costs, and the more often the wave has a
+    // pixel inside a triangle's box and its lanes walk their columns and rows in the rare path.
+    // How often depends on the size of the triangles on the screen, for which their number
+    // stands in: measured at 3840x2160, a million triangles sweep in 17.4 ms with 1024 pixels per
+    // lane, 20.6 with 512 and 27.5 with 256; 100 000 in 3.4, 2.7 and 3.9 ms (4.3 with 128); 69 000
+    // in 3.3, 3.2 and 3.6; 6 000 fastest with 128.
+    const int widest = tiles >= 4096 ? 1024 : (tiles >= 256 ? 512 : 128);
+    if (r > widest) r = widest;
     while (r > 1 && RT_RASTER_COLS * r > W + RT_RASTER_COLS * r / 2) r /= 2;    // no wave mostly off the image
     // more pixels per lane cost fewer instructions per pair, but their wider tiles may cover
     // more pixels beyond the image's edges: take the cheaper product
@@ -1092,11 +1103,7 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
         // one-tile chunk does not repay it: the 6 k-triangle mesh at 4K sweeps in 0.6 ms with 128
         // pixels per lane and in 1.2 ms with 256)
         const long long_chunks = tiles / 2 < 1 ? 1 : (tiles / 2 < max_chunks ? tiles / 2 : max_chunks);
-        bool enough = rt_raster_tiles(W, rows, r, best_layout(r)) * long_chunks >= 4 * slots;
-        // (the widest lanes only for large meshes: on the 69 k- and 100 k-triangle closed meshes at
-        // 4K, whose triangles are larger on the screen, a 1024-pixel wave enters the rare path
-        // often enough for 128 pixels per lane to win, 3.7 against 4.3 ms and 4.4 against 4.6)
-        if (r > 128 && tiles < 1024) enough = false;
+        const bool enough = rt_raster_tiles(W, rows, r, best_layout(r)) * long_chunks >= 4 * slots;
         if (cost <= cost_half && enough) break;
         r /= 2;
     }
@@ -1107,6 +1114,8 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
             static const int rounds = getenv("RT_AMD_RASTER_ROUNDS") ? atoi(getenv("RT_AMD_RASTER_ROUNDS")) : 24;
             long c = (rounds * slots + wgs - 1) / wgs;  // about 24 rounds are fine-grained enough
             if (c > max_chunks) c = max_chunks;
+            // (a workgroup of wide lanes has more to set up: its chunks keep two tiles)
+            if (r >= 256 && c > (tiles / 2 < 1 ? 1 : tiles / 2)) c = tiles / 2 < 1 ? 1 : tiles / 2;
             if (c < 1) c = 1;
             *pixels_per_lane = r;
             *chunks = (int)c;
@@ -1160,6 +1169,12 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
 #endif
 #if RT_RASTER_RPL >= 256
         RT_RASTER_CASE(256)
+#endif
+#if RT_RASTER_RPL >= 512
+        RT_RASTER_CASE(512)
+#endif
+#if RT_RASTER_RPL >= 1024
+        RT_RASTER_CASE(1024)
 #endif
     }
 #undef RT_RASTER_CASE
