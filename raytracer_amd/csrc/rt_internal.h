@@ -66,7 +66,7 @@ constexpr int RT_RAYS_PER_WG = RT_WG * RT_RPL;
 // Sweeps of rays through a common point (rt_sweep_apex.hip): the eye for primary rays, a
 // light for its shadow rays.  4 float4 planes per triangle, packed per apex by k_pack_apex.
 #ifndef RT_RASTER_RPL
-#define RT_RASTER_RPL 1024  // most pixels per lane of the primary (pixel-grid) sweep
+#define RT_RASTER_RPL 2048  // most pixels per lane of the primary (pixel-grid) sweep
 #endif
 #define RT_RASTER_COLS 4     // pixel columns a lane's pixels are apart (a wave is COLS R x 64/COLS pixels)
 #ifndef RT_APEX_RPL
@@ -78,7 +78,11 @@ constexpr int RT_LIGHT_PLANES = RT_APEX_PLANES + 3;
 constexpr int RT_APEX_LIGHTS = 4;   // lights swept per any-hit launch (plane sets kept side by side)
 constexpr int RT_APEX_SETS = 3 * RT_APEX_LIGHTS;    // ray sets per launch: light x dominant axis
 // A lane's rpl pixels in the pixel-grid sweep are a block of this many rows (by rpl / rows columns).
-constexpr int rt_raster_lane_rows(int rpl) { return rpl >= 256 ? 16 : (rpl >= 64 ? 8 : (rpl >= 16 ? 4 : (rpl >= 4 ? 2 : 1))); }
+constexpr int rt_raster_lane_rows(int rpl) { return rpl >= 2048 ? 32 : (rpl >= 256 ? 16 : (rpl >= 64 ? 8 : (rpl >= 16 ? 4 : (rpl >= 4 ? 2 : 1)))); }
+// A wave's 64 lanes cover this many local rows (two 16-row blocks from 2048 pixels per lane on) ...
+constexpr int rt_raster_wave_rows(int rpl) { return rpl >= 2048 ? 2 * RT_TILE_H : RT_TILE_H; }
+// ... by this many pixel columns
+constexpr int rt_raster_wave_cols(int rpl) { return 64 * rpl / rt_raster_wave_rows(rpl); }
 // Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels = rows x columns): the
 // distance of the first column from the box's centre and one addition for each further column,
 // one subtraction per row, a three-way minimum per two columns and per two rows (`logic`) and
@@ -310,17 +314,17 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
 // RT_RASTER_COLS * pixels_per_lane x RT_TILE_H pixels; waves wholly off the image idle)
 inline long rt_raster_pairs(int W, int rows, int pixels_per_lane, long tris)
 {
-    const int ww = RT_RASTER_COLS * pixels_per_lane;
-    return (long)((W + ww - 1) / ww) * ((rows + RT_TILE_H - 1) / RT_TILE_H) * (64L * pixels_per_lane) * tris;
+    const int ww = rt_raster_wave_cols(pixels_per_lane), wh = rt_raster_wave_rows(pixels_per_lane);
+    return (long)((W + ww - 1) / ww) * ((rows + wh - 1) / wh) * (64L * pixels_per_lane) * tris;
 }
 // workgroup tiles that shape needs to cover W x rows pixels
 inline long rt_raster_tiles(int W, int rows, int pixels_per_lane, int waves_x)
 {
     if (waves_x == 0) {
-        const int ww = RT_RASTER_COLS * pixels_per_lane;
-        return ((long)((W + ww - 1) / ww) * ((rows + RT_TILE_H - 1) / RT_TILE_H) + 3) / 4;
+        const int ww = rt_raster_wave_cols(pixels_per_lane), wh = rt_raster_wave_rows(pixels_per_lane);
+        return ((long)((W + ww - 1) / ww) * ((rows + wh - 1) / wh) + 3) / 4;
     }
-    const int tw = waves_x * RT_RASTER_COLS * pixels_per_lane, th = RT_TILE_H * (4 / waves_x);
+    const int tw = waves_x * rt_raster_wave_cols(pixels_per_lane), th = rt_raster_wave_rows(pixels_per_lane) * (4 / waves_x);
     return (long)((W + tw - 1) / tw) * ((rows + th - 1) / th);
 }
 int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st);     // any-hit over binned ray lists

@@ -192,10 +192,12 @@ __device__ __forceinline__ void finish_raster(const SweepArgs& A, long slot, int
 template <int R>
 struct RasterLane {
     static constexpr int RY = rt_raster_lane_rows(R), RX = R / RY;
-    static constexpr int SY = RT_TILE_H / RY;                   // local rows between a lane's rows
-    static constexpr int SX = RT_RASTER_COLS * RY;              // pixels between a lane's columns
-    static constexpr float KX = (float)(SX / RT_RASTER_COLS);   // the same in the boxes' x unit
-    static_assert(SX * SY == 64 && SX * RX == RT_RASTER_COLS * R, "the lanes' lattices tile the wave's pixels");
+    static constexpr int WH = rt_raster_wave_rows(R), WW = rt_raster_wave_cols(R);   // the wave's pixels
+    static constexpr int SY = WH / RY;                          // local rows between a lane's rows
+    static constexpr int SX = 64 / SY;                          // pixels between a lane's columns
+    static constexpr float KX = (float)SX / (float)RT_RASTER_COLS;   // the same in the boxes' x unit
+    static_assert(SX * SY == 64 && SX * RX == WW && SY * RY == WH && SX % RT_RASTER_COLS == 0,
+                  "the lanes' lattices tile the wave's pixels");
 };
 
 template <int R>
@@ -292,7 +294,8 @@ __device__ __forceinline__ void stage_boxes(const float4* __restrict__ boxes, in
 // the same either way; what changes is that most (pixel, triangle) pairs are then decided 64 R
 // at a time instead of one by one.
 template <int R, bool CULL>
-__global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : RT_RASTER_WAVES) k_sweep_raster(const SweepArgs A)
+__global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : (R >= 2048 ? RT_RASTER_WAVES - 2 : RT_RASTER_WAVES))
+k_sweep_raster(const SweepArgs A)
 {
     // (one more entry: the read-ahead of the all-pairs loop touches the one behind the second buffer)
     __shared__ float4 tile_lds[2 * RT_CULL_GROUP * RT_TILE + 1];
@@ -310,23 +313,23 @@ __global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : RT_RASTER_WAVES) 
     constexpr int COLS = RT_RASTER_COLS;
     using L = RasterLane<R>;
     constexpr int RY = L::RY, SX = L::SX, SY = L::SY;
-    static_assert(64 / COLS == RT_TILE_H, "a wave covers RT_TILE_H rows");
+    constexpr int WW = L::WW, WH = L::WH;
     // the four waves: waves_x side by side, the rest below (whichever wastes fewer pixels beyond
     // the image's right and bottom edges)
     // ... or, waves_x = 0, the wave-sized blocks of the band numbered row by row and dealt four
     // to a workgroup: no idle waves but in the last workgroup
     int wave_x0, wave_y0;
     if (A.waves_x == 0) {
-        const int cols = (A.W + COLS * R - 1) / (COLS * R);
+        const int cols = (A.W + WW - 1) / WW;
         const int w = blockIdx.x * 4 + wave, wy = w / cols;
-        wave_x0 = (w - wy * cols) * (COLS * R);
-        wave_y0 = wy * RT_TILE_H;
+        wave_x0 = (w - wy * cols) * WW;
+        wave_y0 = wy * WH;
     } else {
-        const int wx = A.waves_x, tile_w = wx * (COLS * R), tile_h = RT_TILE_H * (4 / wx);
+        const int wx = A.waves_x, tile_w = wx * WW, tile_h = WH * (4 / wx);
         const int tiles_x = (A.W + tile_w - 1) / tile_w;
         const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-        wave_x0 = txi * tile_w + (wave & (wx - 1)) * (COLS * R);
-        wave_y0 = tyi * tile_h + (wave / wx) * RT_TILE_H;
+        wave_x0 = txi * tile_w + (wave & (wx - 1)) * WW;
+        wave_y0 = tyi * tile_h + (wave / wx) * WH;
     }
     const int px0 = wave_x0 + lane % SX;
     const int lr0 = wave_y0 + lane / SX;                            // first local row of the call's row set
@@ -338,7 +341,7 @@ __global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : RT_RASTER_WAVES) 
         Y[j] = lr0 + SY * j < A.rows.rows ? (float)(A.rows.image_row(lr0 + SY * j) - A.H / 2) : __builtin_nanf("");
     // the same per local row of the wave, in LDS, for the rare path (which indexes it by a row
     // number of its own in every lane): the lanes of a wave that share a row write the same value
-    __shared__ float row_y[RT_WG / 64][RT_TILE_H];
+    __shared__ float row_y[RT_WG / 64][WH];
 #pragma unroll
     for (int j = 0; j < RY; ++j) row_y[wave][lane / SX + SY * j] = Y[j];
     const float* y_of_row = &row_y[wave][lane / SX];
@@ -352,7 +355,7 @@ __global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : RT_RASTER_WAVES) 
     if constexpr (CULL) {
         // columns wave_x0 .. the wave's last one on the image; rows: the image rows of the wave's
         // local rows that exist (an interleaved row part maps them anywhere)
-        const int x_last = wave_x0 + COLS * R - 1 < A.W - 1 ? wave_x0 + COLS * R - 1 : A.W - 1;
+        const int x_last = wave_x0 + WW - 1 < A.W - 1 ? wave_x0 + WW - 1 : A.W - 1;
         const float xa = (float)(wave_x0 - A.W / 2), xb = (float)(x_last - A.W / 2);
         float ya = INF, yb = -INF;              // (the minimum and maximum pass over a missing row's NaN)
 #pragma unroll
@@ -1056,7 +1059,7 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     // pixels the workgroup tiles cover, and the wave layout that covers the fewest (waves wholly
     // beyond the image's edges do no arithmetic, but they hold registers and LDS)
     auto covered = [&](int r, int wx) {
-        const long tw = (long)wx * RT_RASTER_COLS * r, th = RT_TILE_H * (4 / wx);
+        const long tw = (long)wx * rt_raster_wave_cols(r), th = rt_raster_wave_rows(r) * (4 / wx);
         return ((W + tw - 1) / tw) * tw * (((rows + th - 1) / th) * th);
     };
     // pixels the working waves cover: what the arithmetic is paid for
@@ -1071,7 +1074,7 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
         const int n = sscanf(force, "%d,%d,%d", &fr, &fc, &fw);
         if (n >= 2 && fc >= 1 && fc <= (tiles < 1 ? 1 : tiles) &&
             (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == 16 || fr == 32 || fr == 64 || fr == 128 || fr == 256 ||
-             fr == 512 || fr == 1024) &&
+             fr == 512 || fr == 1024 || fr == 2048) &&
             fr <= RT_RASTER_RPL) {
             *pixels_per_lane = fr;
             *chunks = fc;
@@ -1086,24 +1089,25 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     // 4096 pixels wide), the fewer instructions a pair costs, and the more often the wave has a
     // pixel inside a triangle's box and its lanes walk their columns and rows in the rare path.
     // How often depends on the size of the triangles on the screen, for which their number
-    // stands in: measured at 3840x2160, a million triangles sweep in 17.4 ms with 1024 pixels per
-    // lane, 20.6 with 512 and 27.5 with 256; 100 000 in 3.4, 2.7 and 3.9 ms (4.3 with 128); 69 000
-    // in 3.3, 3.2 and 3.6; 6 000 fastest with 128.
-    const int widest = tiles >= 4096 ? 1024 : (tiles >= 256 ? 512 : 128);
+    // stands in: measured at 3840x2160, a million triangles sweep in 12.7 ms with 2048 pixels per
+    // lane (64 columns of 32 rows: the wave is 4096 x 32 pixels and the kernel needs 80 registers),
+    // 17.4 with 1024, 20.6 with 512 and 27.5 with 256; 100 000 in 3.4 (1024), 2.7 and 3.9 ms (4.3
+    // with 128); 69 000 in 3.3, 3.2 and 3.6; 6 000 fastest with 128.
+    const int widest = tiles >= 4096 ? 2048 : (tiles >= 256 ? 512 : 128);
     if (r > widest) r = widest;
-    while (r > 1 && RT_RASTER_COLS * r > W + RT_RASTER_COLS * r / 2) r /= 2;    // no wave mostly off the image
+    while (r > 1 && rt_raster_wave_cols(r) > W + rt_raster_wave_cols(r) / 2) r /= 2;    // no wave mostly off the image
     // more pixels per lane cost fewer instructions per pair, but their wider tiles may cover
     // more pixels beyond the image's edges: take the cheaper product
     while (r > 8) {
         const RasterMix m = rt_raster_mix(r), h = rt_raster_mix(r / 2);
         const double cost = (double)(m.fma + m.add + m.logic + m.compare) / r * swept(r);
         const double cost_half = (double)(h.fma + h.add + h.logic + h.compare) / (r / 2) * swept(r / 2);
-        // ... unless the wider lanes leave too few workgroups for four rounds of the machine with
+        // ... unless the wider lanes leave too few workgroups for two rounds of the machine with
         // chunks of at least two tiles (a workgroup of wide lanes has more to set up, and a
         // one-tile chunk does not repay it: the 6 k-triangle mesh at 4K sweeps in 0.6 ms with 128
         // pixels per lane and in 1.2 ms with 256)
         const long long_chunks = tiles / 2 < 1 ? 1 : (tiles / 2 < max_chunks ? tiles / 2 : max_chunks);
-        const bool enough = rt_raster_tiles(W, rows, r, best_layout(r)) * long_chunks >= 4 * slots;
+        const bool enough = rt_raster_tiles(W, rows, r, best_layout(r)) * long_chunks >= 2 * slots;
         if (cost <= cost_half && enough) break;
         r /= 2;
     }
@@ -1175,6 +1179,9 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
 #endif
 #if RT_RASTER_RPL >= 1024
         RT_RASTER_CASE(1024)
+#endif
+#if RT_RASTER_RPL >= 2048
+        RT_RASTER_CASE(2048)
 #endif
     }
 #undef RT_RASTER_CASE

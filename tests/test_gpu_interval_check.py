@@ -33,7 +33,7 @@ for mesh in meshes:
 """
 
 
-@pytest.mark.parametrize("shape", [None, "256,3,0", "512,2,0", "1024,3,0", "128,4,1", "64,4,1", "32,4,2", "16,3,4", "8,2,1", "32,5,0"])
+@pytest.mark.parametrize("shape", [None, "256,3,0", "512,2,0", "1024,3,0", "2048,2,0", "128,4,1", "64,4,1", "32,4,2", "16,3,4", "8,2,1", "32,5,0"])
 def test_no_pass_outside_the_interval(shape):
     if not os.path.exists(CHECK_LIB):
         pytest.fail("raytracer_amd/librt_amd_check.so is missing: run __graft_entry__.build()")
