@@ -86,7 +86,7 @@ constexpr int rt_raster_wave_cols(int rpl) { return 64 * rpl / rt_raster_wave_ro
 // Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels = rows x columns): the
 // distance of the first column from the box's centre and one addition for each further column,
 // one subtraction per row, a three-way minimum per two columns and per two rows (`logic`) and
-// two compares: 122 instructions per 1024 pairs (16 rows x 64 columns), 5/64 of a flop per pair.  Any-hit apex
+// two compares: 146 instructions per 2048 pairs (32 rows x 64 columns), 3/64 of a flop per pair.  Any-hit apex
 // sweep, per pair: one subtraction (the u half of the bounding-square test), a three-way minimum
 // per two pairs and a compare per eight: 13 instructions per 8 pairs, one flop per pair.
 struct RasterMix { int fma, add, logic, compare; };

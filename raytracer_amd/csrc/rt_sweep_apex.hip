@@ -34,8 +34,8 @@
 //                   triangle's projection onto the image plane (k_pack_apex writes one per
 //                   triangle, allowances included).  A pixel is in the box when its column is
 //                   in the box's x extent and its row in the y extent, so a lane evaluates one
-//                   interval test per column and per row of its lattice -- 122 VALU instructions
-//                   per 1024 pairs (64 columns, 16 rows) -- and every pixel's verdict is the one it would get on its
+//                   interval test per column and per row of its lattice -- 146 VALU instructions
+//                   per 2048 pairs (64 columns, 32 rows) -- and every pixel's verdict is the one it would get on its
 //                   own.  Primary rays leave P, which fixes the sign of det for a hit, so
 //                   k_pack_apex orients every triangle (sign layout) for the rare path's
 //                   inside test.
@@ -1041,8 +1041,8 @@ int rt_device_cus()
 // triangle range into chunks that run as separate workgroups makes the rounds shorter and fills
 // small bands.  The chunks of a pixel share its candidate list and closest-hit bound (atomics in
 // the rare path), so their number costs neither memory nor pruning: about 24 rounds of
-// workgroups, 904 chunks for a 3840x2160 frame of a million triangles at 1024 pixels per lane, the
-// cap of RT_RASTER_MAX_CHUNKS for an eighth of it.  A chunk may be as short as one tile (measured: a 6 k-triangle mesh at 3840x2160 sweeps in
+// workgroups: the cap of RT_RASTER_MAX_CHUNKS for a 3840x2160 frame of a million triangles at 2048
+// pixels per lane (17 workgroups of pixels) and for an eighth of it.  A chunk may be as short as one tile (measured: a 6 k-triangle mesh at 3840x2160 sweeps in
 // 2.7 ms with 49 one-tile chunks, 3.3 ms with 6 chunks of 8); a mesh too small to fill the machine
 // even so gives up pixels per lane instead.  RT_AMD_RASTER_FORCE="<pixels per lane>,<chunks>[,<waves side by
 // side, 0 = dealt row by row>]" overrides the choice (read at every call: tests use it to run
