@@ -259,6 +259,14 @@ typedef struct rt_profile {
     uint64_t exact_candidates;  /* fp64 confirmations */
     uint64_t exact_overflow;    /* rays that fell back to the full fp64 sweep */
     uint64_t rays_live;         /* generic-ray launches: rays in use (unused slots excluded) */
+    /* any-hit phases that ran as a sweep over lattices of direction cells (their time, launches and
+     * ray-triangle pairs are part of shadow_ms / shadow_launches / shadow_tests as well) */
+    double   cell_ms;
+    uint64_t cell_launches;
+    uint64_t cell_pairs;        /* (cell, triangle) pairs: one first test each, what the hot loop executes */
+    uint64_t cell_ray_pairs;    /* (ray, triangle) pairs behind it, tested one by one */
+    uint64_t cell_rays;         /* rays swept that way */
+    uint64_t cells_per_lane;    /* kernel shape of the most recent such launch */
 } rt_profile;
 /* Compile-time shape of the sweep kernel for rays in general position (rt_trace_rays,
  * rt_occluded): formulation (2 = moment form), triangles per LDS tile, rays per lane, and the

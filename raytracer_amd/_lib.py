@@ -59,6 +59,12 @@ class RtProfile(C.Structure):
         ("exact_candidates", C.c_uint64),
         ("exact_overflow", C.c_uint64),
         ("rays_live", C.c_uint64),
+        ("cell_ms", C.c_double),
+        ("cell_launches", C.c_uint64),
+        ("cell_pairs", C.c_uint64),
+        ("cell_ray_pairs", C.c_uint64),
+        ("cell_rays", C.c_uint64),
+        ("cells_per_lane", C.c_uint64),
     ]
 
 

@@ -11,7 +11,7 @@ FLAGS=(-O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -I"$root/inc
 objs=()
 bdir="${RT_AMD_BUILD_DIR:-$here/build}"
 mkdir -p "$bdir"
-for src in rt_sweep.hip rt_sweep_apex.hip rt_sort.hip rt_exact.hip rt_transform.hip rt_shade.hip rt_api.hip rt_multi.hip rt_sequence.hip rt_host.cpp rt_obj.cpp; do
+for src in rt_sweep.hip rt_sweep_apex.hip rt_sweep_cells.hip rt_sort.hip rt_exact.hip rt_transform.hip rt_shade.hip rt_api.hip rt_multi.hip rt_sequence.hip rt_host.cpp rt_obj.cpp; do
   obj="$bdir/${src%.*}.o"
   if [ ! -f "$obj" ] || [ "$here/$src" -nt "$obj" ] || [ "$here/rt_internal.h" -nt "$obj" ] || [ "$here/rt_sweep_common.h" -nt "$obj" ] || [ "$root/include/rt_amd.h" -nt "$obj" ]; then
     echo "hipcc $src"

@@ -215,7 +215,8 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts,
                       &sc->scratch_max, &sc->mat_dev, &sc->ws_partials, &sc->ws_frame, &sc->planes_light, &sc->ws_sort_tri, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
-                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort, &sc->tri_order};
+                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort, &sc->tri_order,
+                      &sc->ws_cell_rays, &sc->ws_cell_table, &sc->ws_cell_boxes};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : sc->tex_data) b.release();
     if (sc->h_counts) (void)hipHostFree(sc->h_counts);
@@ -745,9 +746,28 @@ extern "C" int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int
 // launch(a) starts one range for all sets.
 constexpr int kCountSlots = 48;     // ranges of one any-hit sweep whose counts can be in flight
 
+// The sizes of `sets` binned ray lists (counts_dev, on the device) on the host: the one thing the
+// host waits for before an any-hit phase.
+static int binned_counts(rt_scene* sc, const int* counts_dev, int sets, int* out)
+{
+    hipStream_t st = rt_g().stream;
+    if (!sc->h_counts) {
+        RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&sc->h_counts), sizeof(int) * RT_APEX_SETS * kCountSlots,
+                             hipHostMallocDefault));
+        sc->count_events.resize(kCountSlots);
+        for (hipEvent_t& e : sc->count_events) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    RT_HIP(hipMemcpyAsync(sc->h_counts, counts_dev, sizeof(int) * sets, hipMemcpyDeviceToHost, st));
+    RT_HIP(hipEventRecord(sc->count_events[0], st));
+    RT_HIP(hipEventSynchronize(sc->count_events[0]));
+    for (int k = 0; k < sets; ++k) out[k] = sc->h_counts[k];
+    return RT_OK;
+}
+
+// known (or nullptr): the sizes of the binned lists when the caller has fetched them already
 template <class Launch>
 static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride, bool binned,
-                         Launch&& launch)
+                         Launch&& launch, const int* known = nullptr)
 {
     hipStream_t st = rt_g().stream;
     const int np = sc->num_tris_padded;
@@ -792,7 +812,14 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
         return RT_OK;
     };
     int slot_next = 0;          // slot the next post goes to
-    if (binned) {               // the sizes of the binned lists: these the host does wait for
+    if (binned && known) {
+        live = 0; total = 0;
+        for (int k = 0; k < sets; ++k) { live = known[k] > live ? known[k] : live; total += known[k]; }
+        est = total;
+        // (the ray sort below reads the counts from the first slot of the host array)
+        for (int k = 0; k < sets; ++k) sc->h_counts[k] = known[k];
+        ++slot_next;
+    } else if (binned) {        // the sizes of the binned lists: these the host does wait for
         RT_TRY(post_counts(live_dev[0], slot_next));
         RT_TRY(take_counts(slot_next));
         ++slot_next;
@@ -869,6 +896,62 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
         indexed = true;
         len = (int)(len * growth + RT_TILE - 1) / RT_TILE * RT_TILE;
     }
+    return RT_OK;
+}
+
+// Whether the any-hit phase of `total` binned shadow rays runs as a sweep over lattices of
+// direction cells (rt_sweep_cells.hip) or as the ray-by-ray sweep in triangle ranges
+// (rt_sweep_apex.hip).  RT_AMD_SHADOW_LATTICE = 0 / 1 forces one or the other (read at every call:
+// tests run both on the same inputs); otherwise the lattice takes every phase large enough to
+// repay its ray sort.  Tile culling keeps the ray-by-ray sweep, which it is defined on.
+static bool use_cell_lattice(long total, int np)
+{
+    if (rt_tile_culling()) return false;
+    if (const char* e = getenv("RT_AMD_SHADOW_LATTICE")) return atoi(e) != 0;
+    static const double min_pairs = getenv("RT_AMD_LATTICE_MIN_PAIRS") ? atof(getenv("RT_AMD_LATTICE_MIN_PAIRS")) : 2e10;
+    return (double)total * (double)np >= min_pairs;
+}
+
+// One any-hit phase over the binned lists (lists + s * stride, counts[s] rays) as a cell-lattice
+// sweep: no triangle ranges, no compaction, one sweep launch.
+static int anyhit_cells(rt_scene* sc, SweepArgs a, int sets, long stride, const int32_t* lists, const int* counts)
+{
+    RtGlobal& g = rt_g();
+    hipStream_t st = g.stream;
+    a.light_ray_stride = stride;
+    CellPlan plan{};
+    RT_TRY(rt_cells_prepare(sc, a, lists, counts, sets, st, &plan));
+    if (plan.rays == 0) return RT_OK;
+    if (getenv("RT_AMD_TRACE_PASSES"))
+        fprintf(stderr, "rt_amd: cell sweep: %ld rays in %d set(s), %ld cells (%d per lane, %ld footprints), %d chunks\n",
+                plan.rays, plan.args.sets, plan.cells, plan.cells_per_lane, plan.footprints, plan.chunks);
+    if (!g.profiling) return rt_cells_launch(plan, st);
+    plan.args.ray_pairs = a.tests;
+    RT_HIP(hipMemsetAsync(a.tests, 0, sizeof(unsigned long long), st));
+    RT_HIP(hipEventRecord(g.ev0, st));
+    RT_TRY(rt_cells_launch(plan, st));
+    RT_HIP(hipEventRecord(g.ev1, st));
+    RT_HIP(hipEventSynchronize(g.ev1));
+    float ms = 0;
+    RT_HIP(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+    unsigned long long t = 0;
+    RT_HIP(hipMemcpyAsync(&t, a.tests, sizeof t, hipMemcpyDeviceToHost, st));
+    RT_HIP(hipMemsetAsync(a.tests, 0, sizeof t, st));
+    RT_HIP(hipStreamSynchronize(st));
+    g.prof.shadow_ms += ms;
+    g.prof.shadow_launches++;
+    // pairs decided: every listed ray against every triangle; what the hot loop executes is one
+    // test per (cell, triangle) pair, and the rare path one per (ray, triangle) pair it visits
+    g.prof.shadow_tests += (uint64_t)plan.rays * (uint64_t)a.num_tris_padded;
+    g.prof.cell_ms += ms;
+    g.prof.cell_launches++;
+    g.prof.cell_pairs += (uint64_t)plan.cells * (uint64_t)a.num_tris_padded;
+    g.prof.cell_ray_pairs += t;
+    g.prof.cell_rays += (uint64_t)plan.rays;
+    g.prof.cells_per_lane = (uint64_t)plan.cells_per_lane;
+    if (getenv("RT_AMD_TRACE_PASSES"))
+        fprintf(stderr, "rt_amd: cell sweep: %.3f ms, %.3e cell-triangle pairs (%.2e /s), %.3e ray-triangle pairs one by one\n",
+                ms, (double)plan.cells * a.num_tris_padded, (double)plan.cells * a.num_tris_padded / (ms * 1e-3), (double)t);
     return RT_OK;
 }
 
@@ -1029,10 +1112,19 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
         int32_t* act0 = sc->ws_act0.as<int32_t>();
         int* live0 = sc->ws_live.as<int>();
         auto sweep = [&](const SweepArgs& r) { return rt_launch_sweep_apex(r, st); };
+        // one any-hit phase over the lists binned into act0 / live0
+        auto phase = [&]() -> int {
+            int counts[RT_APEX_SETS];
+            RT_TRY(binned_counts(sc, live0, sets, counts));
+            long total = 0;
+            for (int k = 0; k < sets; ++k) total += counts[k];
+            if (use_cell_lattice(total, sc->num_tris_padded)) return anyhit_cells(sc, a, sets, (long)npix, act0, counts);
+            return anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep, counts);
+        };
         RT_HIP(hipMemsetAsync(sc->ws_live.p, 0, sizeof(int) * 3 * RT_APEX_SETS, st));
         if (!use_cache) {
             RT_TRY(rt_launch_bin_rays(a.S, a.E, hit, W, nrows, lights, (long)npix, 1, 0, act0, live0, st));
-            RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
+            RT_TRY(phase());
             continue;
         }
         // Occluder cache (k_try_cached), coarse to fine: the rays of every 4th pixel in x and y
@@ -1057,7 +1149,7 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
                 RT_TRY(rt_launch_compact(a.cnt, act2, live2, (int)npix, sets, (long)npix, 3, act0, live0,
                                          sc->ws_live.as<int>() + 3 * RT_APEX_SETS, st));
             }
-            RT_TRY(anyhit_ranges(sc, a, (int)npix, sets, (long)npix, true, sweep));
+            RT_TRY(phase());
         }
     }
     return resolve_rays(sc, scene_workspace(sc), (int)(npix * (size_t)L), S, E, true, nullptr, nullptr, nullptr, occ,

@@ -164,6 +164,9 @@ struct rt_scene {
     // per-call workspaces (grow-only)
     DevBuf ws_cnt, ws_list, ws_ovf, ws_counters, ws_besthi, ws_partials, ws_frame;
     DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_act2, ws_live, ws_occid, ws_sort;
+    // the cell-lattice any-hit sweep (rt_sweep_cells.hip): sort space and ray records, the cell
+    // table, the triangles' boxes in cell units
+    DevBuf ws_cell_rays, ws_cell_table, ws_cell_boxes;
 };
 
 struct DevMaterial {
@@ -357,6 +360,56 @@ constexpr int RT_COMPACT_SLICES = 2048;
 int rt_launch_compact(const int32_t* cnt, const int32_t* in, const int* in_counts, int n, int sets,
                       long stride, int cnt_div, int32_t* out, int* out_counts, int* slice_counts,
                       hipStream_t st);
+
+// rt_sweep_cells.hip: the any-hit sweep of binned shadow-ray lists over lattices of direction
+// cells.  A ray set (light, dominant axis) is a set of points (u, v) in [-1, 1]^2 on the plane
+// D_k = 1 through the light; the square is cut into 2^gu x 2^gv cells, a ray belongs to the cell
+// its fp32 (u, v) falls into, and the sweep tests every (cell, triangle) pair -- the triangle's
+// bounding square grown by half a cell against the cell's centre, separably per column and per
+// row of a lane's lattice of cells like the pixel-grid sweep -- and behind that every ray of a
+// passing cell against the square and the inside test on its own.
+struct CellSet {
+    int light, axis;        // of the launch's group of lights; dominant axis 0..2
+    int gu_log2, gv_log2;   // the set's grid: 2^gu columns (u) by 2^gv rows (v)
+    int cell_base;          // first entry of the set in the cell table
+    int fp_base;            // first footprint (the block of cells one wave owns) of the set
+    int fp_cols_log2;       // footprints side by side in a row of the grid
+    int ray_base, rays;     // the set's rays in the launch's sorted arrays (host's count)
+    int list;               // which of the caller's binned lists the set is (light * 3 + axis)
+};
+struct CellArgs {
+    CellSet set[RT_APEX_SETS];
+    int sets;               // sets with rays (empty ones are left out)
+    const float4* boxes;    // per set and plane entry: (cx, rx, cy, ry) in cell units, sets x num_tris_padded
+    const float4* planes;   // the lights' plane sets (four apex planes + three planes of squares each)
+    long plane_stride, light_plane_stride;
+    int num_tris_padded;
+    int tri_begin, tri_end; // tile-aligned
+    const int2* table;      // per cell: [begin, end) in rays[] / slot[]
+    float4* rays;           // sorted by cell: (u, v, len, sig); u = NaN once the ray has retired
+    const int32_t* slot;    // the ray's entry in cnt / list / occ_id
+    int32_t *cnt, *list, *occ_id;
+    const int32_t* tri_order;   // entry k of light l's planes holds triangle tri_order[l * num_tris_padded + k] (nullptr: k)
+    unsigned long long* ray_pairs;  // (ray, triangle) pairs tested one by one, accumulated (may be nullptr)
+};
+struct CellPlan {
+    CellArgs args;
+    int cells_per_lane;     // 2048, 512, 128 or 32: the kernel shape
+    int chunks;             // triangle chunks (blockIdx.y)
+    long cells, footprints, rays;
+};
+// Per-lane cells of the lattice shapes and what their hot loop costs per lane and triangle
+constexpr int rt_cells_lane_rows(int r) { return r >= 2048 ? 32 : (r >= 512 ? 16 : (r >= 128 ? 8 : (r >= 32 ? 4 : 2))); }
+constexpr int RT_CELLS_SX = 8, RT_CELLS_SY = 8;     // a wave's 64 lanes are the 8 x 8 phases of the lattice
+constexpr int rt_cells_wave_cols(int r) { return RT_CELLS_SX * (r / rt_cells_lane_rows(r)); }
+constexpr int rt_cells_wave_rows(int r) { return RT_CELLS_SY * rt_cells_lane_rows(r); }
+constexpr int rt_cells_instr(int r) { return r / rt_cells_lane_rows(r) * 3 / 2 + rt_cells_lane_rows(r) * 3 / 2 + 2; }
+// Sorts the listed rays of every set into cells, scales the triangles' squares to each set's
+// grid and fills `plan`; a.S/E/cnt/list/occ_id/tri_order/planes as for rt_launch_sweep_apex,
+// lists = the binned ray numbers (set s at lists + s * a.light_ray_stride, counts_host[s] of them).
+int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, const int* counts_host,
+                     int sets, hipStream_t st, CellPlan* plan);
+int rt_cells_launch(const CellPlan& plan, hipStream_t st);
 
 // rt_exact.hip
 struct ExactScene {

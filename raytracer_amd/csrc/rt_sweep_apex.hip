@@ -83,18 +83,6 @@ constexpr int kRasterUnroll = RT_RASTER_UNROLL;
 constexpr int kApexUnroll = RT_APEX_UNROLL;
 
 struct Tri2 { float4 P, Q; };
-// LDS by its 32-bit address (a float4 of HIP is a class, which a pointer into another address
-// space cannot be dereferenced as; the native vector can)
-typedef float native_float4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned lds_address(const void* p)
-{
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
-}
-__device__ __forceinline__ float4 lds_read_float4(unsigned at)
-{
-    const native_float4 v = *(const __attribute__((address_space(3))) native_float4*)(size_t)at;
-    return make_float4(v.x, v.y, v.z, v.w);
-}
 
 __device__ __forceinline__ Tri2 load_tri2(const float4* p) { return {p[0], p[RT_TILE]}; }
 
@@ -114,29 +102,6 @@ __device__ __forceinline__ void push_mem(const SweepArgs& A, long slot, int tri)
 {
     const int c = atomicAdd(&A.cnt[slot], 1);
     if (c < RT_RASTER_LIST_K) A.list[slot * RT_RASTER_LIST_K + c] = tri;
-}
-
-// min(a, |b|, |c|) as the one instruction it is (the optimiser otherwise turns the chain of these
-// over a lane's pixels into separate two-operand minima)
-__device__ __forceinline__ float min3_abs(float a, float b, float c)
-{
-    float r;
-    asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// max(|a|, |b|) and min(a, b, c), likewise one instruction each
-__device__ __forceinline__ float max_abs(float a, float b)
-{
-    float r;
-    asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float min3_plain(float a, float b, float c)
-{
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
 }
 
 // The inside test for one pixel that lies in the bounding box of triangle `tri` (candidate() of
@@ -469,38 +434,6 @@ __device__ __forceinline__ float dot_ax(float u, float v, const float4& p)
     if (AX == 0) return __builtin_fmaf(u, p.y, __builtin_fmaf(v, p.z, p.x));     // D' = (1, u, v)
     if (AX == 1) return __builtin_fmaf(u, p.x, __builtin_fmaf(v, p.z, p.y));     // D' = (u, 1, v)
     return __builtin_fmaf(u, p.x, __builtin_fmaf(v, p.y, p.z));                  // D' = (u, v, 1)
-}
-
-// The counterpart of candidate() for an any-hit sweep whose triangle range is shared by several
-// workgroups per ray: the candidate count and the occluded flag of a ray live in global memory
-// only and are updated atomically.  The order of a ray's list entries is then arbitrary, which
-// an any-hit query does not care about (triangle_intersection.cu:169 asks for any dist > 0).
-// Returns true when the pair is a certain hit (the ray retires).
-__device__ __forceinline__ bool candidate_shared(int32_t* __restrict__ cnt_slot,
-                                                 int32_t* __restrict__ list_slot,
-                                                 int32_t* __restrict__ occ_slot, int tri, float a,
-                                                 float b, float w, float d, float T, float t0,
-                                                 float margin, float en, float eT)
-{
-    const float ad = __builtin_fabsf(d);
-    const float den = ad - en;
-    bool certain = false;
-    if (den > 0.0f) {
-        const float q = T / d;
-        const float t = t0 + q;
-        const float terr = (eT + __builtin_fabsf(q) * en) / den * 1.000001f +
-                           U22 * (__builtin_fabsf(t0) + __builtin_fabsf(q));
-        if (!(t >= -terr)) return false;
-        certain = (__builtin_fminf(__builtin_fminf(a, b), w) >= margin * ad) && (t > terr);
-    }
-    if (certain) {
-        atomicOr(cnt_slot, RT_CNT_OCCLUDED);    // the list no longer matters
-        if (occ_slot) *occ_slot = tri;          // for the occluder cache (any certain occluder will do)
-        return true;
-    }
-    const int at = atomicAdd(cnt_slot, 1) & RT_CNT_MASK;
-    if (at < RT_LIST_K) list_slot[at] = tri;
-    return false;
 }
 
 // The rest of the inside test for one ray (u, v = minor components of D') that passed the slab
