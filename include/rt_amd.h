@@ -267,6 +267,7 @@ typedef struct rt_profile {
     uint64_t cell_ray_pairs;    /* (ray, triangle) pairs behind it, tested one by one */
     uint64_t cell_rays;         /* rays swept that way */
     uint64_t cells_per_lane;    /* kernel shape of the most recent such launch */
+    uint64_t cell_lookups;      /* cell-table look-ups of the rare path */
 } rt_profile;
 /* Compile-time shape of the sweep kernel for rays in general position (rt_trace_rays,
  * rt_occluded): formulation (2 = moment form), triangles per LDS tile, rays per lane, and the

@@ -65,6 +65,7 @@ class RtProfile(C.Structure):
         ("cell_ray_pairs", C.c_uint64),
         ("cell_rays", C.c_uint64),
         ("cells_per_lane", C.c_uint64),
+        ("cell_lookups", C.c_uint64),
     ]
 
 

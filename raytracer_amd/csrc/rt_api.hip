@@ -216,7 +216,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
                       &sc->scratch_max, &sc->mat_dev, &sc->ws_partials, &sc->ws_frame, &sc->planes_light, &sc->ws_sort_tri, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
                       &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort, &sc->tri_order,
-                      &sc->ws_cell_rays, &sc->ws_cell_table, &sc->ws_cell_boxes};
+                      &sc->ws_cell_rays, &sc->ws_cell_table, &sc->ws_cell_boxes, &sc->ws_cell_wide};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : sc->tex_data) b.release();
     if (sc->h_counts) (void)hipHostFree(sc->h_counts);
@@ -926,18 +926,20 @@ static int anyhit_cells(rt_scene* sc, SweepArgs a, int sets, long stride, const 
         fprintf(stderr, "rt_amd: cell sweep: %ld rays in %d set(s), %ld cells (%d per lane, %ld footprints), %d chunks\n",
                 plan.rays, plan.args.sets, plan.cells, plan.cells_per_lane, plan.footprints, plan.chunks);
     if (!g.profiling) return rt_cells_launch(plan, st);
-    plan.args.ray_pairs = a.tests;
-    RT_HIP(hipMemsetAsync(a.tests, 0, sizeof(unsigned long long), st));
+    plan.args.ray_pairs = a.tests;      // (the counter block's bytes 8..15 and 24..31)
+    RT_HIP(hipMemsetAsync(a.tests, 0, 7 * sizeof(unsigned long long), st));
     RT_HIP(hipEventRecord(g.ev0, st));
     RT_TRY(rt_cells_launch(plan, st));
     RT_HIP(hipEventRecord(g.ev1, st));
     RT_HIP(hipEventSynchronize(g.ev1));
     float ms = 0;
     RT_HIP(hipEventElapsedTime(&ms, g.ev0, g.ev1));
-    unsigned long long t = 0;
-    RT_HIP(hipMemcpyAsync(&t, a.tests, sizeof t, hipMemcpyDeviceToHost, st));
-    RT_HIP(hipMemsetAsync(a.tests, 0, sizeof t, st));
+    unsigned long long tt[7] = {0, 0, 0, 0, 0, 0, 0};
+    RT_HIP(hipMemcpyAsync(tt, a.tests, sizeof tt, hipMemcpyDeviceToHost, st));
+    RT_HIP(hipMemsetAsync(a.tests, 0, sizeof tt, st));
     RT_HIP(hipStreamSynchronize(st));
+    const unsigned long long t = tt[0];
+    g.prof.cell_lookups += tt[2];
     g.prof.shadow_ms += ms;
     g.prof.shadow_launches++;
     // pairs decided: every listed ray against every triangle; what the hot loop executes is one
@@ -950,8 +952,8 @@ static int anyhit_cells(rt_scene* sc, SweepArgs a, int sets, long stride, const 
     g.prof.cell_rays += (uint64_t)plan.rays;
     g.prof.cells_per_lane = (uint64_t)plan.cells_per_lane;
     if (getenv("RT_AMD_TRACE_PASSES"))
-        fprintf(stderr, "rt_amd: cell sweep: %.3f ms, %.3e cell-triangle pairs (%.2e /s), %.3e ray-triangle pairs one by one\n",
-                ms, (double)plan.cells * a.num_tris_padded, (double)plan.cells * a.num_tris_padded / (ms * 1e-3), (double)t);
+        fprintf(stderr, "rt_amd: cell sweep: %.3f ms, %.3e cell-triangle pairs (%.2e /s), %.3e ray-triangle pairs one by one, %.3e cell look-ups, %.3e wave entries\n",
+                ms, (double)plan.cells * a.num_tris_padded, (double)plan.cells * a.num_tris_padded / (ms * 1e-3), (double)t, (double)tt[2], (double)tt[3]);
     return RT_OK;
 }
 

@@ -166,7 +166,7 @@ struct rt_scene {
     DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_act2, ws_live, ws_occid, ws_sort;
     // the cell-lattice any-hit sweep (rt_sweep_cells.hip): sort space and ray records, the cell
     // table, the triangles' boxes in cell units
-    DevBuf ws_cell_rays, ws_cell_table, ws_cell_boxes;
+    DevBuf ws_cell_rays, ws_cell_table, ws_cell_boxes, ws_cell_wide;
 };
 
 struct DevMaterial {
@@ -385,19 +385,25 @@ struct CellArgs {
     long plane_stride, light_plane_stride;
     int num_tris_padded;
     int tri_begin, tri_end; // tile-aligned
-    const int2* table;      // per cell: [begin, end) in rays[] / slot[]
-    float4* rays;           // sorted by cell: (u, v, len, sig); u = NaN once the ray has retired
+    const int* table;       // cells + 1 entries: rays in the cells before this one; the rays of cell c are rays[table[c] .. table[c + 1])
+    float2* rays;           // sorted by cell: (u, v); u = NaN once the ray has retired
+    const float2* len_sig;  // same order: |light - S| and 1 / (unit direction)_k, for the rare path's ray parameter
     const int32_t* slot;    // the ray's entry in cnt / list / occ_id
     int32_t *cnt, *list, *occ_id;
     const int32_t* tri_order;   // entry k of light l's planes holds triangle tri_order[l * num_tris_padded + k] (nullptr: k)
-    unsigned long long* ray_pairs;  // (ray, triangle) pairs tested one by one, accumulated (may be nullptr)
+    unsigned long long* ray_pairs;  // (ray, triangle) pairs tested one by one, accumulated (may be nullptr);
+                                    // [2]: cell-table look-ups, [3]: rare-path entries of waves
+    int debug_skip;                 // measurement only: leave the rare path out (wrong results)
 };
 struct CellPlan {
     CellArgs args;
     int cells_per_lane;     // 2048, 512, 128 or 32: the kernel shape
     int chunks;             // triangle chunks (blockIdx.y)
     long cells, footprints, rays;
+    const int* wide;        // per set: the triangles swept ray by ray instead (k_cell_boxes)
+    int largest_set;        // rays of the largest set
 };
+constexpr int RT_CELLS_WIDE_CAP = 2048;     // wide triangles a set's list holds
 // Per-lane cells of the lattice shapes and what their hot loop costs per lane and triangle
 constexpr int rt_cells_lane_rows(int r) { return r >= 2048 ? 32 : (r >= 512 ? 16 : (r >= 128 ? 8 : (r >= 32 ? 4 : 2))); }
 constexpr int RT_CELLS_SX = 8, RT_CELLS_SY = 8;     // a wave's 64 lanes are the 8 x 8 phases of the lattice

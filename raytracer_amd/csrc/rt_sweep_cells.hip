@@ -66,7 +66,7 @@ struct CellCtx {
 
 // The rest for one ray that lies in the triangle's square: finish_apex of rt_sweep_apex.hip with
 // the planes' components already permuted for the set's axis (D' . p = u pu + v pv + pk).
-__device__ __forceinline__ bool finish_cell(const CellArgs& A, const CellCtx& X, const float4& rec, int i, int tri,
+__device__ __forceinline__ bool finish_cell(const CellArgs& A, const CellCtx& X, const float2& rec, int i, int tri,
                                             const float (&Pp)[3], float margin, const float (&Hp)[3], float Hw,
                                             const float (&Np)[3], float en)
 {
@@ -81,35 +81,47 @@ __device__ __forceinline__ bool finish_cell(const CellArgs& A, const CellCtx& X,
         const float w = __builtin_fmaf(d, d, -a) - b;
         const float m3 = __builtin_fminf(__builtin_fminf(a, b), w);
         if (!(__builtin_fmaf(margin, __builtin_fabsf(d), m3) > 0.0f)) return false;
-        // rec.z = len = |light - S|, rec.w = sig = 1 / (unit direction)_k: t = len + sig * k / (D'.nn)
-        const float T = rec.w * Hw;
+        // len = |light - S|, sig = 1 / (unit direction)_k: t = len + sig * k / (D'.nn)
+        const float2 ls = A.len_sig[i];
+        const float T = ls.y * Hw;
         return candidate_shared(A.cnt + sl, A.list + (long)sl * RT_LIST_K, A.occ_id ? A.occ_id + sl : nullptr, real,
-                                a, b, w, d, T, rec.z, margin, en, U22 * __builtin_fabsf(T));
+                                a, b, w, d, T, ls.x, margin, en, U22 * __builtin_fabsf(T));
     }
     const int at = atomicAdd(A.cnt + sl, 1) & RT_CNT_MASK;
     if (at < RT_LIST_K) A.list[(long)sl * RT_LIST_K + at] = real;
     return false;
 }
 
-// A lane with a column and a row of its lattice inside the grown box: the cells of the box, and
-// the rays of those cells one by one.  d0, e0: distance of the lane's first column / row from
-// the box's centre (cell units); col0, row0: that first cell.
+// Some cell of the wave lies inside the triangle's grown box.  The cells of the wave's footprint
+// whose centre is in the box form a rectangle of the grid, and because the rays are sorted by
+// cell, row by row, the rays of one row of the rectangle are one run of the ray array: from the
+// first ray at or behind the row's first cell to the first ray behind its last (the cell table
+// holds, for every cell, the number of rays in the cells before it).  The whole wave works
+// through the rectangle together: a lane per row looks up the row's run, and the rays found are
+// dealt to the lanes one each (a running sum over the rows' ray counts and a search in it,
+// through lane permutes) -- a lane's own cells hold anything from no ray to hundreds, and walked
+// lane by lane the wave would wait for its busiest lane's chain of dependent loads.  Every ray
+// of every such cell is tested against the triangle on its own.
+// box: the triangle's (cx, rx, cy, ry), wave-uniform; fx0, fy0: the first cell of the footprint.
 template <int R>
-__device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, const float4& box, int tri, float d0,
-                                           float e0, int col0, int row0, unsigned& tested)
+__device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, const float4& vbox, int tri, int fx0,
+                                           int fy0, int lane, unsigned& tested, unsigned& visited)
 {
     using L = CellLane<R>;
-    constexpr float KX = (float)L::SX, KY = (float)L::SY;
-    // the columns and rows of the box, one more on either side for the rounding of these bounds
-    // (each is tested again below with the hot loop's own expression)
-    int c_lo = (int)__builtin_floorf(__builtin_fmaxf((-box.y - d0) * (1.0f / KX), 0.0f)) - 1;
-    int c_hi = (int)__builtin_ceilf(__builtin_fminf((box.y - d0) * (1.0f / KX), (float)(L::RX - 1))) + 1;
-    int j_lo = (int)__builtin_floorf(__builtin_fmaxf((-box.w - e0) * (1.0f / KY), 0.0f)) - 1;
-    int j_hi = (int)__builtin_ceilf(__builtin_fminf((box.w - e0) * (1.0f / KY), (float)(L::RY - 1))) + 1;
-    c_lo = c_lo < 0 ? 0 : c_lo;
-    c_hi = c_hi > L::RX - 1 ? L::RX - 1 : c_hi;
-    j_lo = j_lo < 0 ? 0 : j_lo;
-    j_hi = j_hi > L::RY - 1 ? L::RY - 1 : j_hi;
+    // (scalar copies: every bound below is wave-uniform and the loops run on scalar counters)
+    const float bx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.x)));
+    const float rx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.y)));
+    const float by = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.z)));
+    const float ry = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.w)));
+    // The cells to visit: integer centres x with |x - cx| <= rho hu + 1/2 for the exact centre and
+    // extent.  The stored extent exceeds that by 2^-9 cell, more than the roundings of the stored
+    // centre and of the two bounds here, so the integers between the computed bounds include them.
+    const float xl = __builtin_fmaxf(bx - rx, (float)fx0), xh = __builtin_fminf(bx + rx, (float)(fx0 + L::WW - 1));
+    const float yl = __builtin_fmaxf(by - ry, (float)fy0), yh = __builtin_fminf(by + ry, (float)(fy0 + L::WH - 1));
+    if (!(xl <= xh) || !(yl <= yh)) return;
+    const int x_lo = (int)__builtin_ceilf(xl), y_lo = (int)__builtin_ceilf(yl);
+    const int nx = (int)__builtin_floorf(xh) - x_lo + 1, ny = (int)__builtin_floorf(yh) - y_lo + 1;
+    if (nx <= 0 || ny <= 0) return;
     // the triangle's square in (u, v) and its planes (tri is wave-uniform)
     const float4* __restrict__ g = X.planes + tri;
     const float4 sq = g[X.square_plane];
@@ -121,17 +133,42 @@ __device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, 
     const float Hp[3] = {ax == 0 ? Hh.y : Hh.x, ax == 2 ? Hh.y : Hh.z, ax == 0 ? Hh.x : (ax == 1 ? Hh.y : Hh.z)};
     const float Np[3] = {ax == 0 ? N.y : N.x, ax == 2 ? N.y : N.z, ax == 0 ? N.x : (ax == 1 ? N.y : N.z)};
     const float qnan = __builtin_nanf("");
-    for (int j = j_lo; j <= j_hi; ++j) {
-        if (!(__builtin_fabsf(e0 + KY * (float)j) <= box.w)) continue;
-        const int row_cell = X.cell_base + ((row0 + L::SY * j) << X.gu_log2) + col0;
-        for (int c = c_lo; c <= c_hi; ++c) {
-            if (!(__builtin_fabsf(d0 + KX * (float)c) <= box.y)) continue;
-            const int2 se = A.table[row_cell + L::SX * c];
-            for (int i = se.x; i < se.y; ++i) {
-                const float4 rec = A.rays[i];
+    const int* __restrict__ table = A.table + X.cell_base;
+    for (int base = 0; base < ny; base += 64) {
+        const int j = base + lane;
+        int first = 0, n = 0;
+        if (j < ny) {
+            const int at = ((y_lo + j) << X.gu_log2) + x_lo;
+            first = table[at];
+            n = table[at + nx] - first;      // (behind a row's last cell comes the next row's first; the table has one more entry than cells)
+            ++visited;
+        }
+        // running sum of the ray counts over the 64 rows
+        int incl = n;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            incl += lane >= off ? t : 0;
+        }
+        const int total = A.debug_skip == 2 ? 0 : __builtin_amdgcn_readlane(incl, 63);
+        const int excl = incl - n;
+
+        for (int r0 = 0; r0 < total; r0 += 64) {
+            const int r = r0 + lane;
+            // the row of ray r: the first one whose running sum exceeds r
+            int l = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) {
+                const int v = __shfl(incl, l + step - 1);
+                l += v <= r ? step : 0;
+            }
+            l = l > 63 ? 63 : l;
+            const int i = __shfl(first, l) + (r - __shfl(excl, l));
+            if (r < total) {
+                const float2 rec = A.rays[i];
                 ++tested;
                 // (a retired ray's u is NaN and never passes)
-                if (max_abs(rec.x - sq.x, rec.y - sq.y) <= sq.z &&
+                if (max_abs(rec.x - sq.x, rec.y - sq.y) <= sq.z && A.debug_skip != 3 &&
                     finish_cell(A, X, rec, i, tri, Pp, margin, Hp, Hh.w, Np, N.w))
                     A.rays[i].x = qnan;
             }
@@ -143,7 +180,8 @@ __device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, 
 // box = (cx, rx, cy, ry) in cell units.
 template <int R>
 __device__ __forceinline__ void cells_triangle(const CellArgs& A, const CellCtx& X, const float4& box, int tri,
-                                               float X0, float Y0, int col0, int row0, unsigned& tested)
+                                               float X0, float Y0, int fx0, int fy0, int lane, unsigned& tested,
+                                               unsigned& visited, unsigned& entered)
 {
     using L = CellLane<R>;
     constexpr float KX = (float)L::SX, KY = (float)L::SY;
@@ -157,22 +195,28 @@ __device__ __forceinline__ void cells_triangle(const CellArgs& A, const CellCtx&
 #pragma unroll
     for (int j = 0; j + 1 < L::RY; j += 2)
         accy = min3_abs(accy, j == 0 ? e0 : e0 + KY * (float)j, e0 + KY * (float)(j + 1));
-    if (__builtin_expect(accx <= box.y && accy <= box.w, 0))
-        cells_rare<R>(A, X, box, tri, d0, e0, col0, row0, tested);
+    // some lane has a column and a row of its lattice inside the box: the wave goes through the
+    // box's cells together
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(accx <= box.y && accy <= box.w) != 0, 0)) {
+        ++entered;
+        if (A.debug_skip != 1) cells_rare<R>(A, X, box, tri, fx0, fy0, lane, tested, visited);
+    }
 }
 
-// Stages the boxes of `count` (<= kGroup) consecutive tiles from tile t on.
-__device__ __forceinline__ void stage_cell_boxes(const float4* __restrict__ boxes, int t, int count, float4* buf,
-                                                 int wave, int lane)
+// Stages the boxes of `count` (<= kGroup) tiles: tile t and the ones `stride` tiles further on.
+__device__ __forceinline__ void stage_cell_boxes(const float4* __restrict__ boxes, int t, int stride, int count,
+                                                 float4* buf, int wave, int lane)
 {
-    const float4* src = boxes + (long)t * RT_TILE;
 #pragma unroll
     for (int c = 0; c < (kGroup * (RT_TILE / 64) + 3) / 4; ++c) {
         const int part = c * 4 + wave;
-        if (part < count * (RT_TILE / 64))
+        if (part < count * (RT_TILE / 64)) {
+            const int s = part / (RT_TILE / 64), h = part % (RT_TILE / 64);
+            const float4* src = boxes + (long)(t + s * stride) * RT_TILE + h * 64 + lane;
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(src + part * 64 + lane),
+                (const __attribute__((address_space(1))) void*)src,
                 (__attribute__((address_space(3))) void*)&buf[part * 64], 16, 0, 0);
+        }
     }
 }
 
@@ -208,28 +252,34 @@ k_sweep_cells(const CellArgs A)
 
     const int f = (int)blockIdx.x - cs.fp_base;
     const int fx = f & ((1 << cs.fp_cols_log2) - 1), fy = f >> cs.fp_cols_log2;
-    const int col0 = fx * L::WW + lane % L::SX, row0 = fy * L::WH + lane / L::SX;
-    const float X0 = (float)col0, Y0 = (float)row0;
+    const int fx0 = fx * L::WW, fy0 = fy * L::WH;               // the footprint's first cell
+    const float X0 = (float)(fx0 + lane % L::SX), Y0 = (float)(fy0 + lane / L::SX);   // the lane's first cell
     const float4* __restrict__ boxes = A.boxes + (long)s * A.num_tris_padded;
 
-    // this workgroup's share of the triangle range: chunk blockIdx.y of gridDim.y
+    // This workgroup's share of the triangle range: the tiles blockIdx.y, blockIdx.y + gridDim.y, ...
+    // of it.  The triangles come in the order of their solid angle at the light, largest first,
+    // and a large triangle has many rays inside its square: dealt out tile by tile every chunk
+    // gets its share of those, and every chunk meets its largest triangles first (rays that
+    // are occluded retire early).
     const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
-    const int t_begin = t_first + (int)((long)t_count * blockIdx.y / gridDim.y);
-    const int t_end = t_first + (int)((long)t_count * (blockIdx.y + 1) / gridDim.y);
-    auto group = [&](int t) { return t_end - t < kGroup ? t_end - t : kGroup; };
-    unsigned tested = 0;
-    if (t_begin < t_end) {
-        stage_cell_boxes(boxes, t_begin, group(t_begin), tile[0], wave, lane);
+    const int stride = gridDim.y;
+    const int t0 = t_first + blockIdx.y;
+    const int mine = (int)blockIdx.y < t_count ? (t_count - (int)blockIdx.y + stride - 1) / stride : 0;
+    auto group = [&](int g) { return mine - g < kGroup ? mine - g : kGroup; };
+    unsigned tested = 0, visited = 0, entered = 0;
+    if (mine > 0) {
+        stage_cell_boxes(boxes, t0, stride, group(0), tile[0], wave, lane);
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
     }
     int round = 0;
-    for (int t = t_begin; t < t_end; t += kGroup, ++round) {
-        const int buf = round & 1, count = group(t);
-        if (t + kGroup < t_end) stage_cell_boxes(boxes, t + kGroup, group(t + kGroup), tile[buf ^ 1], wave, lane);
+    for (int g = 0; g < mine; g += kGroup, ++round) {
+        const int buf = round & 1, count = group(g);
+        if (g + kGroup < mine)
+            stage_cell_boxes(boxes, t0 + (g + kGroup) * stride, stride, group(g + kGroup), tile[buf ^ 1], wave, lane);
         const float4* __restrict__ base = tile[buf];
-        const int tri0 = t * RT_TILE + wave * (RT_TILE / 4);
         for (int sub = 0; sub < count; ++sub) {
+            const int tri0 = (t0 + (g + sub) * stride) * RT_TILE + wave * (RT_TILE / 4);
             // (the address in a vector register the compiler cannot see through, advanced once per
             // kUnroll triangles, the reads at immediate offsets, one triangle ahead; the last read
             // of a quarter touches the entry behind it and is not used)
@@ -241,7 +291,7 @@ k_sweep_cells(const CellArgs A)
                 for (int k = 0; k < kUnroll; ++k) {
                     const float4 box = next;
                     next = lds_read_float4(box_at + 16u * (unsigned)(k + 1));
-                    cells_triangle<R>(A, X, box, tri0 + sub * RT_TILE + j4 + k, X0, Y0, col0, row0, tested);
+                    cells_triangle<R>(A, X, box, tri0 + j4 + k, X0, Y0, fx0, fy0, lane, tested, visited, entered);
                 }
                 box_at += 16u * kUnroll;
             }
@@ -249,10 +299,15 @@ k_sweep_cells(const CellArgs A)
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
     }
-    if (A.ray_pairs) {
+    if (A.ray_pairs) {          // [0]: (ray, triangle) pairs tested one by one; [2]: cell-table look-ups
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) tested += __shfl_xor(tested, off);
+        for (int off = 32; off > 0; off >>= 1) {
+            tested += __shfl_xor(tested, off);
+            visited += __shfl_xor(visited, off);
+        }
         if (lane == 0 && tested) atomicAdd(A.ray_pairs, (unsigned long long)tested);
+        if (lane == 0 && visited) atomicAdd(A.ray_pairs + 2, (unsigned long long)visited);
+        if (lane == 0 && entered) atomicAdd(A.ray_pairs + 3, (unsigned long long)entered);
     }
 }
 
@@ -264,12 +319,13 @@ struct CellKeySets {
     int sets;
 };
 
-// blockIdx.y = set.  Ray i of the set: its record (u, v, len, sig) exactly as k_sweep_apex forms
+// blockIdx.y = set.  Ray i of the set: its (u, v) and (len, sig) exactly as k_sweep_apex forms
 // it, its slot, and the number of its cell as the sort key.
 __global__ void __launch_bounds__(RT_WG)
 k_cell_keys(const double* __restrict__ S, const double* __restrict__ E, const int32_t* __restrict__ lists,
             long stride, const int32_t* __restrict__ cnt, CellKeySets ks, unsigned* __restrict__ keys,
-            int32_t* __restrict__ vals, float4* __restrict__ rec, int32_t* __restrict__ slot)
+            int32_t* __restrict__ vals, float2* __restrict__ rec, float2* __restrict__ len_sig,
+            int32_t* __restrict__ slot)
 {
     const CellSet cs = ks.set[blockIdx.y];
     const int axis = cs.axis;
@@ -300,25 +356,40 @@ k_cell_keys(const double* __restrict__ S, const double* __restrict__ E, const in
         const long g = cs.ray_base + i;
         keys[g] = (unsigned)(cs.cell_base + (row << cs.gu_log2) + col);
         vals[g] = (int32_t)g;
-        rec[g] = make_float4(valid ? u : qnan, v, (float)len, (float)sig);
+        rec[g] = make_float2(valid ? u : qnan, v);
+        len_sig[g] = make_float2((float)len, (float)sig);
         slot[g] = (int32_t)sl;
     }
 }
 
-// The records into cell order, and the table: cell -> [begin, end) of its rays.
+// The records into cell order.
 __global__ void __launch_bounds__(RT_WG)
-k_cell_table(const unsigned* __restrict__ keys, const int32_t* __restrict__ vals, int n,
-             const float4* __restrict__ rec_in, const int32_t* __restrict__ slot_in, float4* __restrict__ rec,
-             int32_t* __restrict__ slot, int2* __restrict__ table)
+k_cell_gather(const int32_t* __restrict__ vals, int n, const float2* __restrict__ rec_in,
+              const float2* __restrict__ ls_in, const int32_t* __restrict__ slot_in, float2* __restrict__ rec,
+              float2* __restrict__ ls, int32_t* __restrict__ slot)
 {
     const int j = blockIdx.x * RT_WG + threadIdx.x;
     if (j >= n) return;
     const int src = vals[j];
     rec[j] = rec_in[src];
+    ls[j] = ls_in[src];
     slot[j] = slot_in[src];
-    const unsigned key = keys[j];
-    if (j == 0 || keys[j - 1] != key) table[key].x = j;
-    if (j == n - 1 || keys[j + 1] != key) table[key].y = j + 1;
+}
+
+// The cell table: table[c] = number of rays in the cells before c (a search in the sorted keys),
+// for c = 0 .. cells: the rays of the cells a .. b-1 are rays[table[a] .. table[b]).
+__global__ void __launch_bounds__(RT_WG)
+k_cell_table(const unsigned* __restrict__ keys, int n, int cells, int* __restrict__ table)
+{
+    const int c = blockIdx.x * RT_WG + threadIdx.x;
+    if (c > cells) return;
+    int lo = 0, hi = n;                 // first j with keys[j] >= c
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < (unsigned)c) lo = mid + 1;
+        else hi = mid;
+    }
+    table[c] = lo;
 }
 
 // blockIdx.y = set.  The set's squares (cu, cv, rho) on [-1, 1]^2 in units of its cells: cell c
@@ -326,9 +397,14 @@ k_cell_table(const unsigned* __restrict__ keys, const int32_t* __restrict__ vals
 // a cell (a ray lies within half a cell of its cell's centre) and by 2^-9 cell for the
 // roundings of the sweep's test: the centre's (coordinates below 4096: <= 2^-13 cell), the first
 // subtraction's and each addition's along the lattice (<= 2^-12 each on values below 8192).
+// A triangle whose box would cover more than wide_cells cells of its set's grid (near the light,
+// or with no bound at all) is left out of the lattice (its box never passes) and listed instead:
+// k_cells_wide tests the listed triangles against every ray of the set, ray by ray.  In the
+// lattice one wave alone would walk all the rays of its footprint for such a triangle.  A list
+// that is full leaves the rest to the lattice.  wide: per set, a count and RT_CELLS_WIDE_CAP entries.
 __global__ void __launch_bounds__(RT_WG)
 k_cell_boxes(const float4* __restrict__ planes, long plane_stride, long light_plane_stride, int np, CellKeySets ks,
-             float4* __restrict__ boxes)
+             float wide_cells, float4* __restrict__ boxes, int* __restrict__ wide)
 {
     const int i = blockIdx.x * RT_WG + threadIdx.x;
     if (i >= np) return;
@@ -345,7 +421,64 @@ k_cell_boxes(const float4* __restrict__ planes, long plane_stride, long light_pl
         box = make_float4((float)(((double)sq.x + 1.0) * su - 0.5), (float)((double)sq.z * su + slack) * 1.0000002f,
                           (float)(((double)sq.y + 1.0) * sv - 0.5), (float)((double)sq.z * sv + slack) * 1.0000002f);
     }
+    if (box.y >= 0.0f && !(4.0f * box.y * box.w <= wide_cells)) {
+        int* list = wide + (long)blockIdx.y * (RT_CELLS_WIDE_CAP + 1);
+        const int at = atomicAdd(list, 1);
+        if (at < RT_CELLS_WIDE_CAP) {
+            list[1 + at] = i;
+            box = make_float4(0, -1.0f, 0, -1.0f);
+        }
+    }
     boxes[(long)blockIdx.y * np + i] = box;
+}
+
+// blockIdx.y = set.  Every ray of the set against the set's listed wide triangles: the square
+// test, then the inside test, ray by ray -- what the lattice's rare path does for a cell's rays.
+__global__ void __launch_bounds__(RT_WG)
+k_cells_wide(const CellArgs A, const int* __restrict__ wide)
+{
+    const int s = blockIdx.y;
+    const CellSet cs = A.set[s];
+    const int* list = wide + (long)s * (RT_CELLS_WIDE_CAP + 1);
+    int n = list[0];
+    n = n > RT_CELLS_WIDE_CAP ? RT_CELLS_WIDE_CAP : n;
+    if (n == 0) return;
+    CellCtx X;
+    X.planes = A.planes + (long)cs.light * A.light_plane_stride;
+    X.plane_stride = A.plane_stride;
+    X.square_plane = (long)(RT_APEX_PLANES + cs.axis) * A.plane_stride;
+    X.axis = cs.axis;
+    X.gu_log2 = cs.gu_log2;
+    X.cell_base = cs.cell_base;
+    X.tri_order = A.tri_order ? A.tri_order + (long)cs.light * A.num_tris_padded : nullptr;
+    const int ax = cs.axis;
+    const float qnan = __builtin_nanf("");
+    unsigned tested = 0;
+    for (int k = blockIdx.x * RT_WG + threadIdx.x; k < cs.rays; k += gridDim.x * RT_WG) {
+        const int i = cs.ray_base + k;
+        float2 rec = A.rays[i];
+        for (int w = 0; w < n && rec.x == rec.x; ++w) {
+            const int tri = list[1 + w];
+            const float4* __restrict__ g = X.planes + tri;
+            const float4 sq = g[X.square_plane];
+            ++tested;
+            if (!(max_abs(rec.x - sq.x, rec.y - sq.y) <= sq.z)) continue;
+            const float4 P = g[0], Hh = g[2 * X.plane_stride], N = g[3 * X.plane_stride];
+            const float margin = g[X.plane_stride].w;
+            const float Pp[3] = {ax == 0 ? P.y : P.x, ax == 2 ? P.y : P.z, ax == 0 ? P.x : (ax == 1 ? P.y : P.z)};
+            const float Hp[3] = {ax == 0 ? Hh.y : Hh.x, ax == 2 ? Hh.y : Hh.z, ax == 0 ? Hh.x : (ax == 1 ? Hh.y : Hh.z)};
+            const float Np[3] = {ax == 0 ? N.y : N.x, ax == 2 ? N.y : N.z, ax == 0 ? N.x : (ax == 1 ? N.y : N.z)};
+            if (finish_cell(A, X, rec, i, tri, Pp, margin, Hp, Hh.w, Np, N.w)) {
+                rec.x = qnan;
+                A.rays[i].x = qnan;
+            }
+        }
+    }
+    if (A.ray_pairs) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tested += __shfl_xor(tested, off);
+        if ((threadIdx.x & 63) == 0 && tested) atomicAdd(A.ray_pairs, (unsigned long long)tested);
+    }
 }
 
 int log2_of(int v)
@@ -379,6 +512,13 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     const char* cpr_env = getenv("RT_AMD_CELLS_PER_RAY");
     double cells_per_ray = cpr_env ? atof(cpr_env) : 0.5;
     if (!(cells_per_ray > 0)) cells_per_ray = 0.5;
+    // RT_AMD_CELLS_WIDE: cells a triangle's box may cover before it is swept ray by ray instead
+    // (default: an eighth of a wave's footprint, at least 4096 -- the ray-by-ray kernel costs a
+    // test per ray of the set and triangle, so it is only for the few boxes whose rays one wave
+    // would otherwise walk through alone for milliseconds; measured on the 1 M-triangle frame:
+    // 1024 fills the lists and costs 7 ms, anything from 4096 up to "unbounded boxes only" 5.1 ms)
+    const char* wide_env = getenv("RT_AMD_CELLS_WIDE");
+    float wide_cells = wide_env ? (float)atof(wide_env) : 0.0f;
     int forced_r = 0, forced_chunks = 0;
     if (const char* force = getenv("RT_AMD_CELLS_FORCE")) {
         int fr = 0, fc = 0;
@@ -433,6 +573,10 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     }
     *plan = best;
     if (plan->rays == 0) return RT_OK;
+    if (!(wide_cells > 0.0f)) {
+        wide_cells = (float)(rt_cells_wave_cols(plan->cells_per_lane) * rt_cells_wave_rows(plan->cells_per_lane) / 8);
+        if (wide_cells < 4096.0f) wide_cells = 4096.0f;
+    }
     if (plan->cells >= (1L << 30) || plan->rays >= (1L << 31)) {
         rt_set_error("cell sweep: too many cells or rays for one launch");
         return RT_E_LIMIT;
@@ -459,10 +603,12 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
         rt_set_error("cell sweep: sort size query failed");
         return RT_E_HIP;
     }
-    const size_t a4 = ((size_t)n * 4 + 255) & ~(size_t)255, a16 = ((size_t)n * 16 + 255) & ~(size_t)255;
-    RT_TRY(sc->ws_cell_rays.reserve(6 * a4 + 2 * a16 + temp_bytes));
-    RT_TRY(sc->ws_cell_table.reserve(sizeof(int2) * (size_t)plan->cells));
+    const size_t a4 = ((size_t)n * 4 + 255) & ~(size_t)255, a8 = ((size_t)n * 8 + 255) & ~(size_t)255;
+    RT_TRY(sc->ws_cell_rays.reserve(6 * a4 + 4 * a8 + temp_bytes));
+    RT_TRY(sc->ws_cell_table.reserve(sizeof(int) * ((size_t)plan->cells + 1)));
     RT_TRY(sc->ws_cell_boxes.reserve(sizeof(float4) * (size_t)np * plan->args.sets));
+    RT_TRY(sc->ws_cell_wide.reserve(sizeof(int) * (RT_CELLS_WIDE_CAP + 1) * RT_APEX_SETS));
+    RT_HIP(hipMemsetAsync(sc->ws_cell_wide.p, 0, sizeof(int) * (RT_CELLS_WIDE_CAP + 1) * RT_APEX_SETS, st));
     char* ws = sc->ws_cell_rays.as<char>();
     unsigned* keys_in = reinterpret_cast<unsigned*>(ws);
     unsigned* keys_out = reinterpret_cast<unsigned*>(ws + a4);
@@ -470,9 +616,11 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     int32_t* vals_out = reinterpret_cast<int32_t*>(ws + 3 * a4);
     int32_t* slot_in = reinterpret_cast<int32_t*>(ws + 4 * a4);
     int32_t* slot = reinterpret_cast<int32_t*>(ws + 5 * a4);
-    float4* rec_in = reinterpret_cast<float4*>(ws + 6 * a4);
-    float4* rec = reinterpret_cast<float4*>(ws + 6 * a4 + a16);
-    void* temp = ws + 6 * a4 + 2 * a16;
+    float2* rec_in = reinterpret_cast<float2*>(ws + 6 * a4);
+    float2* rec = reinterpret_cast<float2*>(ws + 6 * a4 + a8);
+    float2* ls_in = reinterpret_cast<float2*>(ws + 6 * a4 + 2 * a8);
+    float2* ls = reinterpret_cast<float2*>(ws + 6 * a4 + 3 * a8);
+    void* temp = ws + 6 * a4 + 4 * a8;
 
     CellKeySets ks{};
     ks.sets = plan->args.sets;
@@ -484,16 +632,19 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     unsigned wgs = (unsigned)((largest + RT_WG - 1) / RT_WG);
     if (wgs > 4096) wgs = 4096;
     hipLaunchKernelGGL(k_cell_keys, dim3(wgs, ks.sets), dim3(RT_WG), 0, st, a.S, a.E, lists, a.light_ray_stride,
-                       a.cnt, ks, keys_in, vals_in, rec_in, slot_in);
+                       a.cnt, ks, keys_in, vals_in, rec_in, ls_in, slot_in);
     RT_HIP(hipGetLastError());
     RT_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (unsigned)n, 0u,
                                      key_bits, st));
-    RT_HIP(hipMemsetAsync(sc->ws_cell_table.p, 0, sizeof(int2) * (size_t)plan->cells, st));
-    hipLaunchKernelGGL(k_cell_table, dim3((unsigned)((n + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0, st, keys_out, vals_out,
-                       n, rec_in, slot_in, rec, slot, sc->ws_cell_table.as<int2>());
+    hipLaunchKernelGGL(k_cell_gather, dim3((unsigned)((n + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0, st, vals_out, n,
+                       rec_in, ls_in, slot_in, rec, ls, slot);
+    RT_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_cell_table, dim3((unsigned)((plan->cells + 1 + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0, st,
+                       keys_out, n, (int)plan->cells, sc->ws_cell_table.as<int>());
     RT_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_cell_boxes, dim3((unsigned)((np + RT_WG - 1) / RT_WG), ks.sets), dim3(RT_WG), 0, st, a.planes,
-                       a.plane_stride, a.light_plane_stride, np, ks, sc->ws_cell_boxes.as<float4>());
+                       a.plane_stride, a.light_plane_stride, np, ks, wide_cells, sc->ws_cell_boxes.as<float4>(),
+                       sc->ws_cell_wide.as<int>());
     RT_HIP(hipGetLastError());
 
     CellArgs& A = plan->args;
@@ -504,20 +655,35 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     A.num_tris_padded = np;
     A.tri_begin = 0;
     A.tri_end = np;
-    A.table = sc->ws_cell_table.as<int2>();
+    A.table = sc->ws_cell_table.as<int>();
     A.rays = rec;
+    A.len_sig = ls;
     A.slot = slot;
     A.cnt = a.cnt;
     A.list = a.list;
     A.occ_id = a.occ_id;
     A.tri_order = a.tri_order;
     A.ray_pairs = nullptr;
+    plan->wide = sc->ws_cell_wide.as<int>();
+    plan->largest_set = largest;
+    A.debug_skip = getenv("RT_AMD_CELLS_SKIP_RARE") ? atoi(getenv("RT_AMD_CELLS_SKIP_RARE")) : 0;
     return RT_OK;
 }
 
 int rt_cells_launch(const CellPlan& plan, hipStream_t st)
 {
     if (plan.rays == 0) return RT_OK;
+    // the wide triangles first: they are the ones most likely to occlude
+    {
+        unsigned wgs = (unsigned)((plan.largest_set + RT_WG - 1) / RT_WG);
+        if (wgs > 8192) wgs = 8192;
+        hipLaunchKernelGGL(k_cells_wide, dim3(wgs, plan.args.sets), dim3(RT_WG), 0, st, plan.args, plan.wide);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            rt_set_error("cell sweep (wide triangles) launch failed: %s", hipGetErrorString(e));
+            return RT_E_HIP;
+        }
+    }
     const dim3 grid((unsigned)plan.footprints, (unsigned)plan.chunks);
     switch (plan.cells_per_lane) {
     case 2048: hipLaunchKernelGGL(k_sweep_cells<2048>, grid, dim3(RT_WG), 0, st, plan.args); break;

@@ -142,6 +142,7 @@ def test_production_scale_against_the_oracle():
     """Culling at the sizes the benchmark runs: the shaded band of the 1 M-triangle 4K frame
     against the oracle (occluder cache, sorted rays, ranged sweeps with compaction in between),
     and the whole 1080p and 4K golden frames."""
-    fullsize.test_config4_soup_1m_4k_shaded_band()
+    fullsize._shaded_rows_vs_oracle(scenes.triangle_soup(1_000_000, seed=12345), 0, 3840, 2160,
+                                    band=(1000, 1064), check_rows=(1003, 1050), min_shadow_launches=8)
     fullsize.test_config2_whole_1080p_frame_against_the_oracles_golden()
     fullsize.test_config3_whole_4k_frame_against_the_oracles_golden()

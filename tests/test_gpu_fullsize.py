@@ -151,10 +151,11 @@ def test_config4_soup_1m_4k_rows():
     sc.close()
 
 
-def _shaded_rows_vs_oracle(mesh, frame_no, W, H, band, check_rows, min_shadow_launches):
+def _shaded_rows_vs_oracle(mesh, frame_no, W, H, band, check_rows, min_shadow_launches, min_cell_launches=0):
     """The whole pixel loop on a band tall enough that the shadow phase takes its production
-    route by itself (default thresholds): occluder cache, rays sorted by direction, triangle
-    ranges with survivor compaction.  Full rows of the band against the oracle's shaded rows."""
+    route by itself (default thresholds): occluder cache, then either the sweep over lattices of
+    direction cells (min_cell_launches) or, with that switched off, rays sorted by direction and
+    triangle ranges with survivor compaction.  Full rows of the band against the oracle's shaded rows."""
     fr = kernel.driver_frame(frame_no)
     obmat = kernel.frame_matrix(fr, "obmat")
     sc = kernel.Scene(mesh)
@@ -165,8 +166,12 @@ def _shaded_rows_vs_oracle(mesh, frame_no, W, H, band, check_rows, min_shadow_la
     out = sc.render_rows(fr, W, H, TAN_HALF, y0, y1)
     prof = kernel.profile_get()
     kernel.profile_enable(False)
-    # several any-hit launches per cache level = the ranged branch ran (a small sweep is one launch)
+    # several any-hit launches per cache level = the ranged branch ran (a small sweep is one launch);
+    # one cell-lattice launch per cache level = the lattice ran
     assert prof.shadow_launches >= min_shadow_launches, prof.shadow_launches
+    assert prof.cell_launches >= min_cell_launches, prof.cell_launches
+    if min_cell_launches == 0:
+        assert prof.cell_launches == 0
     assert prof.rays_shadow > 0 and prof.shadow_tests > 0
     # the same band again without the profiling syncs in between: identical
     again = sc.render_rows(fr, W, H, TAN_HALF, y0, y1, want=("hit", "rgb8"))
@@ -201,6 +206,14 @@ def test_config4_soup_1m_4k_shaded_band():
     1.5e10-pair threshold of the ranged sweeps), two full rows against the oracle
     (light_model.c:60-76: each hit pixel's shadow rays against every triangle)."""
     _shaded_rows_vs_oracle(scenes.triangle_soup(1_000_000, seed=12345), 0, 3840, 2160,
+                           band=(1000, 1064), check_rows=(1003, 1050), min_shadow_launches=2, min_cell_launches=2)
+
+
+def test_config4_soup_1m_4k_shaded_band_ranged_sweeps(monkeypatch):
+    """The same band with the cell lattice switched off: the ray-by-ray any-hit sweep in triangle
+    ranges with survivor compaction, as every phase too small for the lattice runs."""
+    monkeypatch.setenv("RT_AMD_SHADOW_LATTICE", "0")
+    _shaded_rows_vs_oracle(scenes.triangle_soup(1_000_000, seed=12345), 0, 3840, 2160,
                            band=(1000, 1064), check_rows=(1003, 1050), min_shadow_launches=8)
 
 
@@ -209,7 +222,13 @@ def test_config3_bunny_class_4k_shaded_frame():
     mesh (its shadow rays x triangles cross the ranged sweeps' threshold), six full rows against
     the oracle."""
     _shaded_rows_vs_oracle(scenes.torus(69451), 7, 3840, 2160, band=(0, 2160),
-                           check_rows=(200, 700, 1000, 1081, 1400, 1900), min_shadow_launches=5)
+                           check_rows=(200, 700, 1000, 1081, 1400, 1900), min_shadow_launches=2, min_cell_launches=1)
+
+
+def test_config3_bunny_class_4k_shaded_frame_ranged_sweeps(monkeypatch):
+    monkeypatch.setenv("RT_AMD_SHADOW_LATTICE", "0")
+    _shaded_rows_vs_oracle(scenes.torus(69451), 7, 3840, 2160, band=(0, 2160),
+                           check_rows=(200, 1081, 1900), min_shadow_launches=5)
 
 
 def _golden(name):
