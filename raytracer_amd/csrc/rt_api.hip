@@ -655,7 +655,11 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     const size_t npix = (size_t)W * rows.rows;
     if (aside_frame) RT_TRY(lights_fork(sc, aside_lights));
     int rpl = 1, chunks = 1, waves_x = 4;
-    rt_raster_shape(W, rows.rows, sc->num_tris_padded / RT_TILE, &rpl, &chunks, &waves_x);
+    // RT_AMD_RASTER_REGULAR=0: the form with a coordinate per row even where the rows are regular
+    // (read at every call: tests run both on the same inputs)
+    const char* reg_env = getenv("RT_AMD_RASTER_REGULAR");
+    const bool regular = rt_rows_regular(rows) && !rt_tile_culling() && !(reg_env && atoi(reg_env) == 0);
+    rt_raster_shape(W, rows.rows, sc->num_tris_padded / RT_TILE, regular, &rpl, &chunks, &waves_x);
     // per pixel: a count, a bound and RT_RASTER_LIST_K list slots, shared by all triangle chunks
     static_assert(RT_RASTER_LIST_K % RT_LIST_K == 0, "the pixel lists are carved out of the ray lists' buffer");
     RT_TRY(workspaces(sc, npix * (size_t)(RT_RASTER_LIST_K / RT_LIST_K)));
@@ -681,6 +685,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     a.best_hi = sc->ws_besthi.as<float>();
     a.chunks = chunks;
     a.waves_x = waves_x;
+    a.regular = regular ? 1 : 0;
     a.cull = rt_tile_culling() ? 1 : 0;
     a.tests = nullptr;
 #ifdef RT_RASTER_CHECK_INTERVAL

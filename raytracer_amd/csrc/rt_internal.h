@@ -78,9 +78,12 @@ constexpr int RT_LIGHT_PLANES = RT_APEX_PLANES + 3;
 constexpr int RT_APEX_LIGHTS = 4;   // lights swept per any-hit launch (plane sets kept side by side)
 constexpr int RT_APEX_SETS = 3 * RT_APEX_LIGHTS;    // ray sets per launch: light x dominant axis
 // A lane's rpl pixels in the pixel-grid sweep are a block of this many rows (by rpl / rows columns).
-constexpr int rt_raster_lane_rows(int rpl) { return rpl >= 2048 ? 32 : (rpl >= 256 ? 16 : (rpl >= 64 ? 8 : (rpl >= 16 ? 4 : (rpl >= 4 ? 2 : 1)))); }
-// A wave's 64 lanes cover this many local rows (two 16-row blocks from 2048 pixels per lane on) ...
-constexpr int rt_raster_wave_rows(int rpl) { return rpl >= 2048 ? 2 * RT_TILE_H : RT_TILE_H; }
+constexpr int rt_raster_lane_rows(int rpl) { return rpl >= 4096 ? 64 : (rpl >= 2048 ? 32 : (rpl >= 256 ? 16 : (rpl >= 64 ? 8 : (rpl >= 16 ? 4 : (rpl >= 4 ? 2 : 1))))); }
+// A wave's 64 lanes cover this many local rows (two 16-row blocks with 2048 pixels per lane, four with 4096) ...
+constexpr int rt_raster_wave_rows(int rpl) { return rpl >= 4096 ? 4 * RT_TILE_H : (rpl >= 2048 ? 2 * RT_TILE_H : RT_TILE_H); }
+// 4096 pixels per lane (64 rows) exist only in the regular-row form of the sweep, which steps from
+// row to row by a constant instead of holding every row's coordinate in a register
+constexpr int RT_RASTER_RPL_REGULAR = 4096;
 // ... by this many pixel columns
 constexpr int rt_raster_wave_cols(int rpl) { return 64 * rpl / rt_raster_wave_rows(rpl); }
 // Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels = rows x columns): the
@@ -296,6 +299,7 @@ struct SweepArgs {
     int chunks;
     int waves_x;            // pixel-grid sweep only: waves side by side in a workgroup tile (4, 2, 1),
                             // or 0: the waves of the band are numbered row by row and dealt four to a workgroup
+    int regular;            // pixel-grid sweep only: every aligned group of 16 local rows is 16 consecutive image rows
     // pixel-grid sweep only: per pixel, the upper bound of the closest certain hit's t so far
     // (+inf before the sweep); cnt[] must be zero before the sweep
     float* best_hi;
@@ -312,7 +316,9 @@ constexpr int RT_RASTER_MAX_CHUNKS = 1024;
 // below, i.e. workgroup tiles of (waves_x * RT_RASTER_COLS * pixels_per_lane) x (64 / waves_x) pixels;
 // or waves_x = 0: the wave-sized pixel blocks of the band, numbered row by row, four consecutive
 // ones to a workgroup (at most three idle waves in the whole launch; the launcher's own choice)
-void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks, int* waves_x);
+// regular: every aligned group of 16 local rows is 16 consecutive image rows (rt_rows_regular)
+void rt_raster_shape(int W, int rows, int tiles, bool regular, int* pixels_per_lane, int* chunks, int* waves_x);
+inline bool rt_rows_regular(const RowMap& m) { return m.parts == 1 || m.block % 16 == 0; }
 // pixel-triangle pairs the working waves of that shape evaluate (a wave covers
 // RT_RASTER_COLS * pixels_per_lane x RT_TILE_H pixels; waves wholly off the image idle)
 inline long rt_raster_pairs(int W, int rows, int pixels_per_lane, long tris)

@@ -227,6 +227,96 @@ __device__ __forceinline__ void raster_triangle(const SweepArgs& A, const float4
     }
 }
 
+// The same for a lattice whose rows are regular: every aligned group of 16 local rows of the call's
+// row set is 16 consecutive image rows (a contiguous band, or interleaved blocks whose height is
+// a multiple of 16), so within a group the rows' distances from the box's centre step by a
+// constant like the columns', and a lane holds one coordinate per group (YG; NaN for a group
+// beyond the band) instead of one per row: few enough registers for eight waves per SIMD, and
+// room for lattices of 64 rows.  A row of a partly filled last group that does not exist passes
+// like its neighbours would; the rare path asks whether a pixel exists.
+template <int R>
+struct RasterGroups {
+    using L = RasterLane<R>;
+    static constexpr int G = L::WH / RT_TILE_H;     // groups of 16 local rows in a wave
+    static constexpr int RG = L::RY / G;            // rows of a lane's lattice per group
+    static_assert(G >= 1 && RG * G == L::RY, "a lane's rows split evenly over the wave's 16-row groups");
+};
+
+template <int R>
+__device__ __forceinline__ void raster_triangle_reg(const SweepArgs& A, const float4& box, int tri, float Xs0,
+                                                    const float (&YG)[RasterGroups<R>::G], const float* y_of_row,
+                                                    int px0, int lr0, long slot0)
+{
+    using L = RasterLane<R>;
+    constexpr int RX = L::RX, G = RasterGroups<R>::G, RG = RasterGroups<R>::RG;
+    constexpr float KX = L::KX, KY = (float)L::SY;
+    const float d0 = Xs0 - box.x;
+    float accx = INF;
+    if (RX == 1) accx = __builtin_fabsf(d0);
+#pragma unroll
+    for (int c = 0; c + 1 < RX; c += 2)     // (d0 + 0.0f is not d0 to the compiler: it would keep the addition)
+        accx = min3_abs(accx, c == 0 ? d0 : d0 + KX * (float)c, d0 + KX * (float)(c + 1));
+    float e[G];
+    float accy = INF;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        e[g] = YG[g] - box.z;
+        if (RG == 1) accy = __builtin_fminf(accy, __builtin_fabsf(e[g]));
+#pragma unroll
+        for (int j = 0; j + 1 < RG; j += 2)
+            accy = min3_abs(accy, j == 0 ? e[g] : e[g] + KY * (float)j, e[g] + KY * (float)(j + 1));
+    }
+    if (__builtin_expect(accx <= box.y && accy <= box.w, 0)) {
+        // the columns of the box: c with |d0 + KX c| <= rx, one more on either side for the rounding
+        // of these two bounds (the inside test decides about every pixel it is given)
+        int c_lo = (int)__builtin_floorf(__builtin_fmaxf((-box.y - d0) * (1.0f / KX), 0.0f)) - 1;
+        int c_hi = (int)__builtin_ceilf(__builtin_fminf((box.y - d0) * (1.0f / KX), (float)(RX - 1))) + 1;
+        c_lo = c_lo < 0 ? 0 : c_lo;
+        c_hi = c_hi > RX - 1 ? RX - 1 : c_hi;
+#if RT_RASTER_CHECK_INTERVAL
+        {
+            unsigned long long pass = 0;
+#pragma unroll
+            for (int k = 0; k < RX; ++k) pass |= (__builtin_fabsf(d0 + KX * (float)k) <= box.y ? 1ull : 0ull) << k;
+            const unsigned long long inside =
+                c_lo > c_hi ? 0ull : (((c_hi >= 63 ? 0ull : (2ull << c_hi)) - 1ull) & ~((1ull << c_lo) - 1ull));
+            if ((pass & ~inside) && A.tests) atomicAdd(A.tests, 1ull << 48);
+        }
+#endif
+        const float4* __restrict__ g4 = A.planes + tri;
+        const float4 P = g4[0], Hh = g4[2 * A.plane_stride], N = g4[3 * A.plane_stride];
+        const float margin = g4[A.plane_stride].w;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            // the rows of the box in this group, found like the columns (a group beyond the band
+            // carries NaN: its bounds come out as the whole group, and no row of it passes)
+            int j_lo = (int)__builtin_floorf(__builtin_fmaxf((-box.w - e[g]) * (1.0f / KY), 0.0f)) - 1;
+            int j_hi = (int)__builtin_ceilf(__builtin_fminf((box.w - e[g]) * (1.0f / KY), (float)(RG - 1))) + 1;
+            j_lo = j_lo < 0 ? 0 : j_lo;
+            j_hi = j_hi > RG - 1 ? RG - 1 : j_hi;
+#if RT_RASTER_CHECK_INTERVAL
+            {
+                unsigned pass = 0;
+#pragma unroll
+                for (int k = 0; k < RG; ++k) pass |= (__builtin_fabsf(e[g] + KY * (float)k) <= box.w ? 1u : 0u) << k;
+                const unsigned inside = j_lo > j_hi ? 0u : (((j_hi >= 31 ? 0u : (2u << j_hi)) - 1u) & ~((1u << j_lo) - 1u));
+                if ((pass & ~inside) && A.tests) atomicAdd(A.tests, 1ull << 48);
+            }
+#endif
+            for (int jj = j_lo; jj <= j_hi; ++jj) {
+                if (!(__builtin_fabsf(e[g] + KY * (float)jj) <= box.w)) continue;
+                const int j = g * RG + jj;
+                const float Yj = y_of_row[L::SY * j];
+                for (int c = c_lo; c <= c_hi; ++c)
+                    if (__builtin_fabsf(d0 + KX * (float)c) <= box.y &&
+                        px0 + L::SX * c < A.W && lr0 + L::SY * j < A.rows.rows)      // ... and the pixel exists
+                        finish_raster(A, slot0 + (long)(j * L::SY) * A.W + L::SX * c, tri, P, margin, Hh, N,
+                                      Xs0 + KX * (float)c, Yj);
+            }
+        }
+    }
+}
+
 // The pixel rectangle of a wave, for the tile-culling variant: centre and half extents, x in
 // units of RT_RASTER_COLS pixels like the boxes.  Exact in fp32.
 struct WaveRect { float xs_c, xs_h, y_c, y_h; };
@@ -258,10 +348,12 @@ __device__ __forceinline__ void stage_boxes(const float4* __restrict__ boxes, in
 // only the survivors meet the pixels one by one.  The candidates that reach the exact pass are
 // the same either way; what changes is that most (pixel, triangle) pairs are then decided 64 R
 // at a time instead of one by one.
-template <int R, bool CULL>
-__global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : (R >= 2048 ? RT_RASTER_WAVES - 2 : RT_RASTER_WAVES))
+// REG: the rows of the call's row set are regular (raster_triangle_reg).
+template <int R, bool CULL, bool REG>
+__global__ void __launch_bounds__(RT_WG, CULL ? RT_MIN_WAVES : (R >= 2048 && !REG ? RT_RASTER_WAVES - 2 : RT_RASTER_WAVES))
 k_sweep_raster(const SweepArgs A)
 {
+    static_assert(!(CULL && REG), "the tile-culling variant keeps a coordinate per row");
     // (one more entry: the read-ahead of the all-pairs loop touches the one behind the second buffer)
     __shared__ float4 tile_lds[2 * RT_CULL_GROUP * RT_TILE + 1];
     auto tile = reinterpret_cast<float4 (*)[RT_CULL_GROUP * RT_TILE]>(tile_lds);
@@ -300,15 +392,29 @@ k_sweep_raster(const SweepArgs A)
     const int lr0 = wave_y0 + lane / SX;                            // first local row of the call's row set
     // a wave that lies wholly beyond the image's right or bottom edge only helps to stage tiles
     const bool wave_on = __builtin_amdgcn_readfirstlane((wave_x0 < A.W && wave_y0 < A.rows.rows) ? 1 : 0) != 0;
-    float Y[RY];                                                    // driver.c:132; NaN for a row beyond the band
-#pragma unroll
-    for (int j = 0; j < RY; ++j)
-        Y[j] = lr0 + SY * j < A.rows.rows ? (float)(A.rows.image_row(lr0 + SY * j) - A.H / 2) : __builtin_nanf("");
-    // the same per local row of the wave, in LDS, for the rare path (which indexes it by a row
-    // number of its own in every lane): the lanes of a wave that share a row write the same value
+    // driver.c:132 per local row of the wave, in LDS, for the rare path (which indexes it by a row
+    // number of its own in every lane); NaN for a row beyond the band
     __shared__ float row_y[RT_WG / 64][WH];
+    constexpr int NY = REG ? 1 : RY, NG = REG ? RasterGroups<R>::G : 1;
+    float Y[NY];                                                    // every row of the lane's lattice, or ...
+    float YG[NG];                                                   // ... the first one of every 16-row group
+    if constexpr (REG) {
+        static_assert(WH <= 64, "a lane per local row");
+        if (lane < WH)
+            row_y[wave][lane] = wave_y0 + lane < A.rows.rows ? (float)(A.rows.image_row(wave_y0 + lane) - A.H / 2)
+                                                             : __builtin_nanf("");
 #pragma unroll
-    for (int j = 0; j < RY; ++j) row_y[wave][lane / SX + SY * j] = Y[j];
+        for (int g = 0; g < NG; ++g)
+            YG[g] = lr0 + RT_TILE_H * g < A.rows.rows ? (float)(A.rows.image_row(lr0 + RT_TILE_H * g) - A.H / 2)
+                                                      : __builtin_nanf("");
+    } else {
+#pragma unroll
+        for (int j = 0; j < RY; ++j)
+            Y[j] = lr0 + SY * j < A.rows.rows ? (float)(A.rows.image_row(lr0 + SY * j) - A.H / 2) : __builtin_nanf("");
+        // (the lanes of a wave that share a row write the same value)
+#pragma unroll
+        for (int j = 0; j < RY; ++j) row_y[wave][lane / SX + SY * j] = Y[j];
+    }
     const float* y_of_row = &row_y[wave][lane / SX];
     // ray number: local pixel (the triangle chunks of a pixel share its count, list and bound)
     const long slot0 = (long)lr0 * A.W + px0;
@@ -317,7 +423,7 @@ k_sweep_raster(const SweepArgs A)
     // units of COLS pixels, so the sweep works with X / COLS = Xs0 + (SX / COLS) c (exact in fp32)
     const float Xs0 = (float)(px0 - A.W / 2) * (1.0f / COLS);
     WaveRect rect{};
-    if constexpr (CULL) {
+    if constexpr (CULL && !REG) {
         // columns wave_x0 .. the wave's last one on the image; rows: the image rows of the wave's
         // local rows that exist (an interleaved row part maps them anywhere)
         const int x_last = wave_x0 + WW - 1 < A.W - 1 ? wave_x0 + WW - 1 : A.W - 1;
@@ -366,7 +472,7 @@ k_sweep_raster(const SweepArgs A)
                 while (keep) {
                     const int j = h * 64 + __builtin_ctzll(keep);
                     keep &= keep - 1;
-                    raster_triangle<R>(A, base[j], tri0 + j, Xs0, Y, y_of_row, px0, lr0, slot0);
+                    if constexpr (!REG) raster_triangle<R>(A, base[j], tri0 + j, Xs0, Y, y_of_row, px0, lr0, slot0);
                 }
             }
         } else {
@@ -385,7 +491,10 @@ k_sweep_raster(const SweepArgs A)
                     for (int k = 0; k < kRasterUnroll; ++k) {
                         const float4 box = next;
                         next = lds_read_float4(box_at + 16u * (unsigned)(k + 1));
-                        raster_triangle<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, Y, y_of_row, px0, lr0, slot0);
+                        if constexpr (REG)
+                            raster_triangle_reg<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, YG, y_of_row, px0, lr0, slot0);
+                        else
+                            raster_triangle<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, Y, y_of_row, px0, lr0, slot0);
                     }
                     box_at += 16u * kRasterUnroll;
                 }
@@ -980,7 +1089,7 @@ int rt_device_cus()
 // even so gives up pixels per lane instead.  RT_AMD_RASTER_FORCE="<pixels per lane>,<chunks>[,<waves side by
 // side, 0 = dealt row by row>]" overrides the choice (read at every call: tests use it to run
 // every kernel shape on small inputs).
-void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chunks, int* waves_x)
+void rt_raster_shape(int W, int rows, int tiles, bool regular, int* pixels_per_lane, int* chunks, int* waves_x)
 {
     const long slots = 5L * rt_device_cus();           // resident workgroups
     int max_chunks = tiles;                            // a chunk may be a single tile
@@ -991,24 +1100,22 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     if (max_chunks > cap) max_chunks = (int)cap;
     // pixels the workgroup tiles cover, and the wave layout that covers the fewest (waves wholly
     // beyond the image's edges do no arithmetic, but they hold registers and LDS)
-    auto covered = [&](int r, int wx) {
-        const long tw = (long)wx * rt_raster_wave_cols(r), th = rt_raster_wave_rows(r) * (4 / wx);
-        return ((W + tw - 1) / tw) * tw * (((rows + th - 1) / th) * th);
-    };
     // pixels the working waves cover: what the arithmetic is paid for
     auto swept = [&](int r) { return rt_raster_pairs(W, rows, r, 1); };
     // the row-by-row dealing of the waves leaves at most three of them idle in the whole launch
     // (an idle wave does no arithmetic but keeps its slot on a SIMD whose issue rate needs all
     // eight); the rectangular layouts remain for forced shapes
     auto best_layout = [&](int) { return 0; };
-    (void)covered;
+    // most pixels per lane this call can use: 4096 (64 rows) only in the regular-row form, and not
+    // with tile culling
+    const int rpl_max = regular && !rt_tile_culling() ? RT_RASTER_RPL_REGULAR : RT_RASTER_RPL;
     if (const char* force = getenv("RT_AMD_RASTER_FORCE")) {
         int fr = 0, fc = 0, fw = 0;
         const int n = sscanf(force, "%d,%d,%d", &fr, &fc, &fw);
         if (n >= 2 && fc >= 1 && fc <= (tiles < 1 ? 1 : tiles) &&
             (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == 16 || fr == 32 || fr == 64 || fr == 128 || fr == 256 ||
-             fr == 512 || fr == 1024 || fr == 2048) &&
-            fr <= RT_RASTER_RPL) {
+             fr == 512 || fr == 1024 || fr == 2048 || fr == 4096) &&
+            fr <= rpl_max) {
             *pixels_per_lane = fr;
             *chunks = fc;
             *waves_x = (n == 3 && (fw == 0 || fw == 1 || fw == 2 || fw == 4)) ? fw : best_layout(fr);
@@ -1017,7 +1124,7 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     }
     // (with tile culling a wave's pixel rectangle should not be too wide: the narrower, the fewer
     // triangles survive its test; 32 pixels per lane measured best on a 1 M-triangle 4K frame)
-    int r = rt_tile_culling() && RT_RASTER_RPL > 32 ? 32 : RT_RASTER_RPL;
+    int r = rt_tile_culling() && RT_RASTER_RPL > 32 ? 32 : rpl_max;
     // The wider a wave's pixels (a lane of 1024 pixels has 64 columns of 16 rows: the wave is
     // 4096 pixels wide), the fewer instructions a pair costs, and the more often the wave has a
     // pixel inside a triangle's box and its lanes walk their columns and rows in the rare path.
@@ -1026,7 +1133,8 @@ void rt_raster_shape(int W, int rows, int tiles, int* pixels_per_lane, int* chun
     // lane (64 columns of 32 rows: the wave is 4096 x 32 pixels and the kernel needs 80 registers),
     // 17.4 with 1024, 20.6 with 512 and 27.5 with 256; 100 000 in 3.4 (1024), 2.7 and 3.9 ms (4.3
     // with 128); 69 000 in 3.3, 3.2 and 3.6; 6 000 fastest with 128.
-    const int widest = tiles >= 4096 ? 2048 : (tiles >= 256 ? 512 : 128);
+    static const int rows64_tiles = getenv("RT_AMD_RASTER_ROWS64_TILES") ? atoi(getenv("RT_AMD_RASTER_ROWS64_TILES")) : 4096;
+    const int widest = tiles >= rows64_tiles ? 4096 : (tiles >= 4096 ? 2048 : (tiles >= 256 ? 512 : 128));
     if (r > widest) r = widest;
     while (r > 1 && rt_raster_wave_cols(r) > W + rt_raster_wave_cols(r) / 2) r /= 2;    // no wave mostly off the image
     // more pixels per lane cost fewer instructions per pair, but their wider tiles may cover
@@ -1076,17 +1184,24 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
         return RT_E_ARG;
     }
     int r = 1, chunks = 1, wx = 4;
-    rt_raster_shape(a.W, a.rows.rows, (a.tri_end - a.tri_begin) / RT_TILE, &r, &chunks, &wx);
+    const bool regular = a.regular != 0;
+    if (regular && !rt_rows_regular(a.rows)) {
+        rt_set_error("raster sweep: the row set is not regular");
+        return RT_E_ARG;
+    }
+    rt_raster_shape(a.W, a.rows.rows, (a.tri_end - a.tri_begin) / RT_TILE, regular, &r, &chunks, &wx);
     if (a.chunks != chunks || a.waves_x != wx) {
         rt_set_error("raster sweep: caller and launcher disagree on the launch shape (%d chunks, %d waves "
                      "side by side vs %d, %d)", a.chunks, a.waves_x, chunks, wx);
         return RT_E_ARG;
     }
     const dim3 grid((unsigned)rt_raster_tiles(a.W, a.rows.rows, r, wx), chunks);
-#define RT_RASTER_CASE(n)                                                                          \
-    case n:                                                                                        \
-        return a.cull ? launch(k_sweep_raster<n, true>, a, grid, st, "raster sweep (tile culling)") \
-                      : launch(k_sweep_raster<n, false>, a, grid, st, "raster sweep");
+#define RT_RASTER_CASE(n)                                                                                  \
+    case n:                                                                                                \
+        return a.cull ? launch(k_sweep_raster<n, true, false>, a, grid, st, "raster sweep (tile culling)")  \
+                      : (regular ? launch(k_sweep_raster<n, false, true>, a, grid, st, "raster sweep")     \
+                                 : launch(k_sweep_raster<n, false, false>, a, grid, st, "raster sweep"));
+    if (r == 4096 && regular && !a.cull) return launch(k_sweep_raster<4096, false, true>, a, grid, st, "raster sweep");
     switch (r) {
         RT_RASTER_CASE(1)
         RT_RASTER_CASE(2)

@@ -109,7 +109,7 @@ def test_triangles_whose_plane_contains_the_eye(through_eye):
 @pytest.mark.parametrize("shape", ["16,3", "8,2", "2,5", "1,1", "16,2,2", "32,3,1", "64,1", "64,3,4", "64,2,0", "32,5,0"])
 @pytest.mark.parametrize("W,H", [(500, 20), (37, 19)])
 def test_every_shape_of_the_pixel_grid_sweep(shape, W, H, monkeypatch):
-    edge.test_every_shape_of_the_pixel_grid_sweep(shape, W, H, monkeypatch)
+    edge.test_every_shape_of_the_pixel_grid_sweep(shape, W, H, monkeypatch, None)
 
 
 @pytest.mark.parametrize("shape", ["8,1", "8,4", "4,3", "2,2", "1,7"])

@@ -1,6 +1,7 @@
 """The primary sweep's rare path finds the columns of a lane that lie in a triangle's bounding
 box as an interval of column numbers (two subtractions) instead of evaluating every column of the
-lane again.  A checking build of the same sources (raytracer_amd/librt_amd_check.so,
+lane again -- and, in the form of the kernel that steps from row to row by a constant, the rows
+of every 16-row group the same way.  A checking build of the same sources (raytracer_amd/librt_amd_check.so,
 -DRT_RASTER_CHECK_INTERVAL=1) does both and counts the columns the hot loop's own test passes
 that lie outside the interval; there must be none, on hard scenes and for every lane width."""
 import os
@@ -33,11 +34,15 @@ for mesh in meshes:
 """
 
 
-@pytest.mark.parametrize("shape", [None, "256,3,0", "512,2,0", "1024,3,0", "2048,2,0", "128,4,1", "64,4,1", "32,4,2", "16,3,4", "8,2,1", "32,5,0"])
+@pytest.mark.parametrize("shape", [None, "256,3,0", "512,2,0", "1024,3,0", "2048,2,0", "4096,2,0", "4096,5,0", "128,4,1", "64,4,1", "32,4,2",
+                                   "16,3,4", "8,2,1", "32,5,0", "2048,2,0/0", "256,3,0/0", "16,3,4/0"])
 def test_no_pass_outside_the_interval(shape):
     if not os.path.exists(CHECK_LIB):
         pytest.fail("raytracer_amd/librt_amd_check.so is missing: run __graft_entry__.build()")
     env = dict(os.environ, RT_AMD_LIB=CHECK_LIB)
+    if shape and shape.endswith("/0"):          # the form with a coordinate per row
+        shape = shape[:-2]
+        env["RT_AMD_RASTER_REGULAR"] = "0"
     if shape:
         env["RT_AMD_RASTER_FORCE"] = shape
     p = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, os.path.join(ROOT, "tools"))], cwd=ROOT, env=env,
