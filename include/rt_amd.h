@@ -140,15 +140,18 @@ int rt_trace_primary(rt_scene* sc, int W, int H, double tan_half, int y0, int y1
 int rt_trace_rays(rt_scene* sc, int n, const double* S, const double* E,
                   int32_t* hit, double* tuv, double* point);
 
-/* rt_trace_rays for callers that cannot allocate device memory (code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference, whose
+/* rt_trace_rays for callers that cannot allocate device memory (tight serving loops, harnesses
+ * that forbid hipMalloc, code that runs between the captures of HIP graphs; the call itself is
+ * blocking -- it ends with a stream synchronisation -- so it cannot run on a capturing stream).
+ * No counterpart in the reference, whose
  * intersect_all_triangles_device allocates and frees on every call
  * (triangle_intersection.cu:104-165).  Same arguments, outputs and results as rt_trace_rays, but
  * the per-ray workspace (candidate counts and lists, overflow queue, counters: 72 bytes per ray)
  * is a static device array of RT_STATIC_MAX_RAYS entries (about 4.8 MB, held by every GPU the
  * library is initialised on until the process ends) instead of the scene's grow-only buffers:
  * the call performs no hipMalloc / hipFree and no profiling read-back.  n > RT_STATIC_MAX_RAYS
- * returns RT_E_LIMIT.  All calls on one GPU share that array: calls that overlap on a GPU
+ * returns RT_E_LIMIT.  The array used is the copy on the scene's own device, which must be the
+ * current device (RT_E_STATE otherwise, also when rt_init was never run on it).  All calls on one GPU share that array: calls that overlap on a GPU
  * (several host threads or streams) race; calls in sequence do not (each call clears what it
  * needs zeroed and rewrites the rest). */
 #define RT_STATIC_MAX_RAYS 65536

@@ -1189,9 +1189,17 @@ extern "C" int rt_trace_rays_static(rt_scene* sc, int n, const double* S, const 
         return RT_E_LIMIT;
     }
     RtGlobal& g = rt_g();
-    unsigned char* base = g.device >= 0 && g.device < kMaxDevices ? g_scratch_ptr[g.device] : nullptr;
+    // the scene's own device: its copy of the array, and that device must be the current one
+    // (rt_init may since have been run for another GPU of the process)
+    int current = -1;
+    RT_HIP(hipGetDevice(&current));
+    if (current != sc->device) {
+        rt_set_error("rt_trace_rays_static: the scene lives on device %d but device %d is current", sc->device, current);
+        return RT_E_STATE;
+    }
+    unsigned char* base = sc->device >= 0 && sc->device < kMaxDevices ? g_scratch_ptr[sc->device] : nullptr;
     if (!base) {
-        rt_set_error("rt_trace_rays_static: no static workspace on device %d (rt_init not run on it)", g.device);
+        rt_set_error("rt_trace_rays_static: no static workspace on device %d (rt_init not run on it)", sc->device);
         return RT_E_STATE;
     }
     const RayWorkspace ws{reinterpret_cast<int32_t*>(base + kStaticOffCnt),
@@ -1231,6 +1239,15 @@ static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, doubl
     // the first group of lights is sorted and packed on a side stream beside the primary sweep
     static const bool aside_env = !(getenv("RT_AMD_LIGHTS_ASIDE") && atoi(getenv("RT_AMD_LIGHTS_ASIDE")) == 0);
     const bool aside = L > 0 && aside_env;
+    // Work queued on the side stream reads the eye-space vertices and writes the lights' planes.  The
+    // any-hit phase makes the launch stream wait for it; when the call fails before that join
+    // (a reserve, a launch), the side stream is drained here, so that whatever the caller does
+    // next on the launch stream cannot race with it.
+    struct SideJoin {
+        rt_scene* sc;
+        bool armed;
+        ~SideJoin() { if (armed && sc->side_stream) (void)hipStreamSynchronize(sc->side_stream); }
+    } side_join{sc, aside};
     // frame constants: uploaded ahead of the sweep, so that nothing between the sweep and the
     // shading kernels has to wait for the host
     DevBuf& frame_dev = sc->ws_frame;
@@ -1279,6 +1296,7 @@ static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, doubl
     }
     RT_TRY(rt_launch_shade_final(a, st));
     RT_HIP(hipStreamSynchronize(st));
+    side_join.armed = false;        // joined by the any-hit phase, and everything has completed
     return RT_OK;
 }
 

@@ -311,7 +311,7 @@ int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st);
 int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st);   // primary rays, closest hit
 // launch shape of the pixel-grid sweep for a band of W x rows pixels and `tiles` triangle tiles:
 // pixels per lane (<= RT_RASTER_RPL) and the number of triangle chunks (<= RT_RASTER_MAX_CHUNKS)
-constexpr int RT_RASTER_MAX_CHUNKS = 1024;
+constexpr int RT_RASTER_MAX_CHUNKS = 2048;
 // and how the four waves of a workgroup are laid out: waves_x (4, 2 or 1) side by side, the rest
 // below, i.e. workgroup tiles of (waves_x * RT_RASTER_COLS * pixels_per_lane) x (64 / waves_x) pixels;
 // or waves_x = 0: the wave-sized pixel blocks of the band, numbered row by row, four consecutive

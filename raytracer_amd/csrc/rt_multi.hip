@@ -16,7 +16,11 @@
 
 #include <dlfcn.h>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -64,6 +68,17 @@ int load_rccl(Rccl& r)
     return RT_OK;
 }
 
+// The host thread that drives one device for as long as the rt_multi lives: it makes its device
+// current once and then runs the jobs the calls hand it (a thread per device and call cost its
+// creation on every frame).
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;       // set by the caller, cleared by the worker
+    bool has_job = false, done = false, quit = false;
+};
+
 struct Device {
     int ordinal = 0;
     rt_scene* scene = nullptr;
@@ -71,6 +86,7 @@ struct Device {
     hipStream_t comm_stream = nullptr;
     std::string error;              // message of a failed call on this device's thread
     int rc = RT_OK;
+    Worker* worker = nullptr;
 };
 
 }  // namespace
@@ -87,26 +103,92 @@ struct rt_multi {
 
 namespace {
 
-// Runs fn(i) for every device on a thread of its own with that device current; a failure's
+void worker_main(Device* d)
+{
+    Worker& w = *d->worker;
+    const bool device_ok = hipSetDevice(d->ordinal) == hipSuccess;
+    for (;;) {
+        std::function<int()> job;
+        {
+            std::unique_lock<std::mutex> lock(w.mu);
+            w.cv.wait(lock, [&] { return w.has_job || w.quit; });
+            if (w.quit) return;
+            job = std::move(w.job);
+        }
+        int rc = RT_OK;
+        std::string error;
+        if (!device_ok) {
+            rc = RT_E_HIP;
+            error = "hipSetDevice failed";
+        } else {
+            rc = job();
+            if (rc != RT_OK) error = rt_last_error();
+        }
+        {
+            std::lock_guard<std::mutex> lock(w.mu);
+            d->rc = rc;
+            d->error = error;
+            w.has_job = false;
+            w.done = true;
+        }
+        w.cv.notify_all();
+    }
+}
+
+int start_workers(rt_multi* m)
+{
+    for (Device& d : m->dev) {
+        d.worker = new Worker();
+        try {
+            d.worker->th = std::thread(worker_main, &d);
+        } catch (const std::system_error& e) {
+            delete d.worker;
+            d.worker = nullptr;
+            rt_set_error("rt_multi: cannot start the thread of device %d: %s", d.ordinal, e.what());
+            return RT_E_STATE;
+        }
+    }
+    return RT_OK;
+}
+
+void stop_workers(rt_multi* m)
+{
+    for (Device& d : m->dev) {
+        if (!d.worker) continue;
+        {
+            std::lock_guard<std::mutex> lock(d.worker->mu);
+            d.worker->quit = true;
+        }
+        d.worker->cv.notify_all();
+        if (d.worker->th.joinable()) d.worker->th.join();
+        delete d.worker;
+        d.worker = nullptr;
+    }
+}
+
+// Runs fn(i) for every device on that device's thread, with the device current; a failure's
 // message (thread-local in the library) is carried back to the caller's thread.
 template <class F>
 int on_every_device(rt_multi* m, F&& fn)
 {
-    std::vector<std::thread> th;
-    for (size_t i = 0; i < m->dev.size(); ++i)
-        th.emplace_back([&, i] {
-            Device& d = m->dev[i];
-            d.rc = RT_OK;
-            d.error.clear();
-            if (hipSetDevice(d.ordinal) != hipSuccess) {
-                d.rc = RT_E_HIP;
-                d.error = "hipSetDevice failed";
-                return;
-            }
-            d.rc = fn((int)i);
-            if (d.rc != RT_OK) d.error = rt_last_error();
-        });
-    for (std::thread& t : th) t.join();
+    for (size_t i = 0; i < m->dev.size(); ++i) {
+        Device& d = m->dev[i];
+        if (!d.worker) {
+            rt_set_error("rt_multi: device %d has no thread", d.ordinal);
+            return RT_E_STATE;
+        }
+        {
+            std::lock_guard<std::mutex> lock(d.worker->mu);
+            d.worker->job = [&fn, i] { return fn((int)i); };
+            d.worker->has_job = true;
+            d.worker->done = false;
+        }
+        d.worker->cv.notify_all();
+    }
+    for (Device& d : m->dev) {
+        std::unique_lock<std::mutex> lock(d.worker->mu);
+        d.worker->cv.wait(lock, [&] { return d.worker->done; });
+    }
     for (size_t i = 0; i < m->dev.size(); ++i)
         if (m->dev[i].rc != RT_OK) {
             rt_set_error("device %d (part %zu): %s", m->dev[i].ordinal, i, m->dev[i].error.c_str());
@@ -174,6 +256,7 @@ extern "C" int rt_multi_create(rt_multi** out, int n_devices, const int* devices
         }
     }
     if (rc == RT_OK) rc = rt_init(first_device);      // the single-device calls keep their device
+    if (rc == RT_OK) rc = start_workers(m);
     // RT_AMD_MULTI_EXCHANGE=copy: peer copies instead of RCCL (also what a set that names a device
     // twice falls back to: RCCL refuses duplicate devices); =rccl: RCCL even for one device (its
     // part then goes through a send to itself), which rehearses the exchange on a one-GPU machine
@@ -214,6 +297,7 @@ extern "C" int rt_multi_destroy(rt_multi* m)
 {
     if (!m) return RT_OK;
     DeviceGuard guard;
+    stop_workers(m);
     for (ncclComm_t c : m->comms)
         if (c) (void)m->rccl.CommDestroy(c);
     for (Device& d : m->dev) {

@@ -36,6 +36,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -115,6 +117,9 @@ struct Image {
     int w = 0, h = 0;
     std::vector<uint8_t> rgb;
 };
+// A texture file is untrusted input: its header may declare any size.  No decoder allocates for
+// more pixels than this, nor for more than the bytes present could possibly encode.
+constexpr size_t kMaxTexturePixels = (size_t)64 << 20;
 
 bool load_ppm(const std::string& data, Image& im)
 {
@@ -129,6 +134,7 @@ bool load_ppm(const std::string& data, Image& im)
         ++got;
     }
     if (vals[0] <= 0 || vals[1] <= 0 || vals[2] != 255) return false;
+    if ((size_t)vals[0] * (size_t)vals[1] > kMaxTexturePixels) return false;
     ++c.p;      // the single white-space byte after maxval
     const size_t need = (size_t)vals[0] * vals[1] * 3;
     if ((size_t)(c.end - c.p) < need) return false;
@@ -149,7 +155,9 @@ bool load_bmp(const std::string& d, Image& im)
     const int bpp = (uint8_t)d[28] | (uint8_t)d[29] << 8;
     const uint32_t comp = u32(30);
     if (w <= 0 || hs == 0 || (bpp != 24 && bpp != 32) || (comp != 0 && comp != 3)) return false;
+    if (hs == INT32_MIN) return false;
     const int h = hs < 0 ? -hs : hs;
+    if ((size_t)w * (size_t)h > kMaxTexturePixels) return false;
     const size_t stride = ((size_t)w * (bpp / 8) + 3) & ~(size_t)3;
     if (d.size() < off + stride * (size_t)h) return false;
     im.w = w; im.h = h;
@@ -203,6 +211,7 @@ bool load_png(const std::string& d, Image& im)
         o += 12 + (size_t)len;
     }
     if (!have_ihdr || W == 0 || H == 0 || W > 32768 || H > 32768 || idat.empty()) return false;
+    if ((size_t)W * (size_t)H > kMaxTexturePixels) return false;
     int channels;
     switch (ctype) {
     case 0: channels = 1; break;        // grey
@@ -230,6 +239,9 @@ bool load_png(const std::string& d, Image& im)
         if (W <= (uint32_t)pass[k][0] || H <= (uint32_t)pass[k][1] || pw == 0 || ph == 0) continue;
         raw_size += (row_bytes(pw) + 1) * ph;
     }
+    // deflate cannot expand its input by more than a factor of about 1032: a header that asks for
+    // more than the IDAT bytes could hold is refused before anything is allocated for it
+    if (raw_size > idat.size() * 1032 + 4096) return false;
     std::vector<uint8_t> raw(raw_size);
     uLongf got = (uLongf)raw_size;
     if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw_size) return false;
@@ -430,6 +442,15 @@ struct JpegDecoder {
                                            15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55,
                                            62, 63};
         const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+        // every block of every MCU takes at least two bits of entropy-coded data (a DC and an
+        // end-of-block code): a frame header that asks for more MCUs than the bytes left in the
+        // file could hold is refused before its planes are allocated
+        {
+            size_t blocks_per_mcu = 0;
+            for (int c = 0; c < ncomp; ++c) blocks_per_mcu += (size_t)comp[c].h * comp[c].v;
+            const size_t left = pos < n ? n - pos : 0;
+            if ((size_t)W * (size_t)H > kMaxTexturePixels || (size_t)mcux * mcuy * blocks_per_mcu > left * 4 + 64) return false;
+        }
         for (int c = 0; c < ncomp; ++c) {
             Comp& k = comp[c];
             k.stride = mcux * k.h * 8;
@@ -461,7 +482,9 @@ struct JpegDecoder {
                             const int s = decode(dc[k.td]);
                             if (s > 11) return false;
                             k.pred += extend(bits(s), s);
-                            coef[0] = k.pred * qt[k.tq][0];
+                            // (a corrupt stream can drive the prediction anywhere: keep the products in range)
+                            if (k.pred > 32767 || k.pred < -32768) { bad = true; k.pred = 0; }
+                            coef[0] = (int)((long)k.pred * qt[k.tq][0]);
                             for (int i = 1; i < 64;) {
                                 const int rs = decode(ac[k.ta]);
                                 const int r = rs >> 4, sz = rs & 15;
@@ -472,7 +495,7 @@ struct JpegDecoder {
                                 }
                                 i += r;
                                 if (i > 63) return false;
-                                coef[zigzag[i]] = extend(bits(sz), sz) * qt[k.tq][i];
+                                coef[zigzag[i]] = (int)((long)extend(bits(sz), sz) * qt[k.tq][i]);
                                 ++i;
                             }
                             if (bad) return false;
@@ -763,7 +786,14 @@ struct Builder {
     {
         std::string data;
         Image im;
-        if (!read_file(dir + name, data) || !(load_png(data, im) || load_jpeg(data, im) || load_ppm(data, im) || load_bmp(data, im))) {
+        bool decoded = false;
+        try {
+            decoded = read_file(dir + name, data) &&
+                      (load_png(data, im) || load_jpeg(data, im) || load_ppm(data, im) || load_bmp(data, im));
+        } catch (const std::exception&) {       // (out of memory inside a decoder: the map stays unset)
+            decoded = false;
+        }
+        if (!decoded) {
             fprintf(stderr, "rt_obj: cannot decode image map %s%s (kept as a constant colour)\n",
                     dir.c_str(), name.c_str());
             return -1;                                       // IMG_Load failed, :360-363
@@ -889,12 +919,28 @@ T* carve(char*& cur, size_t count)
 
 }  // namespace
 
+static int obj_load_impl(const char* path, rt_obj** out);
+
 extern "C" int rt_obj_load(const char* path, rt_obj** out)
 {
     if (!path || !out) {
         rt_set_error("rt_obj_load: null pointer");
         return RT_E_ARG;
     }
+    // nothing may leave an extern "C" function by exception
+    try {
+        return obj_load_impl(path, out);
+    } catch (const std::bad_alloc&) {
+        rt_set_error("rt_obj_load: out of memory");
+        return RT_E_IO;
+    } catch (const std::exception& e) {
+        rt_set_error("rt_obj_load: %s", e.what());
+        return RT_E_IO;
+    }
+}
+
+static int obj_load_impl(const char* path, rt_obj** out)
+{
     Builder b;
     if (!b.parse(path)) {
         rt_set_error("rt_obj_load: %s", b.err.c_str());

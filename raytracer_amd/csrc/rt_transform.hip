@@ -16,28 +16,43 @@
 
 namespace {
 
+constexpr int kTransformPoints = 8;     // points per lane of k_transform
+
 __global__ void __launch_bounds__(RT_WG)
 k_transform(const double* __restrict__ m, const double* x, const double* y, const double* z,
             double* X, double* Y, double* Z, int n, unsigned* __restrict__ max_bits)
 {
-    const int i = blockIdx.x * RT_WG + threadIdx.x;
+    // kTransformPoints points per lane, so that the largest coordinate costs one atomic per
+    // workgroup and a few thousand per launch (one per wave and point made three million vertices
+    // wait 0.5 ms for 47 000 atomics on one address)
     float mx = 0.0f;
-    if (i < n) {
-        const double xi = x[i], yi = y[i], zi = z[i];
-        const double u = m[0] * xi + m[1] * yi + m[2] * zi + m[3];      // mat_mult.cu:20-22
-        const double v = m[4] * xi + m[5] * yi + m[6] * zi + m[7];
-        const double w = m[8] * xi + m[9] * yi + m[10] * zi + m[11];
-        X[i] = u; Y[i] = v; Z[i] = w;
-        if (i > 0) {        // slot 0 of the 1-indexed arrays is never a real vertex
-            const double a = fmax(fabs(u), fmax(fabs(v), fabs(w)));
-            mx = (a == a && a < 3.0e38) ? (float)a : 0.0f;
+#pragma unroll
+    for (int k = 0; k < kTransformPoints; ++k) {
+        const int i = (blockIdx.x * kTransformPoints + k) * RT_WG + threadIdx.x;
+        if (i < n) {
+            const double xi = x[i], yi = y[i], zi = z[i];
+            const double u = m[0] * xi + m[1] * yi + m[2] * zi + m[3];      // mat_mult.cu:20-22
+            const double v = m[4] * xi + m[5] * yi + m[6] * zi + m[7];
+            const double w = m[8] * xi + m[9] * yi + m[10] * zi + m[11];
+            X[i] = u; Y[i] = v; Z[i] = w;
+            if (i > 0) {        // slot 0 of the 1-indexed arrays is never a real vertex
+                const double a = fmax(fabs(u), fmax(fabs(v), fabs(w)));
+                mx = fmaxf(mx, (a == a && a < 3.0e38) ? (float)a : 0.0f);
+            }
         }
     }
     if (max_bits) {
         // non-negative floats order like their bit patterns
+        __shared__ float wave_max[RT_WG / 64];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-        if ((threadIdx.x & 63) == 0 && mx > 0.0f) atomicMax(max_bits, __float_as_uint(mx));
+        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 1; w < RT_WG / 64; ++w) mx = fmaxf(mx, wave_max[w]);
+            if (mx > 0.0f) atomicMax(max_bits, __float_as_uint(mx));
+        }
     }
 }
 
@@ -367,7 +382,8 @@ int rt_launch_transform(const double* m16, const double* x, const double* y, con
                         double* X, double* Y, double* Z, int n, unsigned* max_bits, hipStream_t st)
 {
     if (n <= 0) return RT_OK;
-    hipLaunchKernelGGL(k_transform, dim3((n + RT_WG - 1) / RT_WG), dim3(RT_WG), 0, st, m16, x, y, z,
+    const int per_wg = RT_WG * kTransformPoints;
+    hipLaunchKernelGGL(k_transform, dim3((n + per_wg - 1) / per_wg), dim3(RT_WG), 0, st, m16, x, y, z,
                        X, Y, Z, n, max_bits);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

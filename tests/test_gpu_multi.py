@@ -48,6 +48,40 @@ def test_multi_frame_equals_single_scene_frame(devices, exchange, monkeypatch):
     ms.close()
 
 
+@pytest.mark.parametrize("exchange", ["rccl", "copy"])
+def test_two_different_gpus(exchange, monkeypatch):
+    """The exchange between two different GPUs, over RCCL (grouped ncclSend / ncclRecv on two
+    communicators and streams) and by peer copies: runs wherever a node with two GPUs exists."""
+    if _lib.load().rt_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    monkeypatch.setenv("RT_AMD_MULTI_EXCHANGE", exchange)
+    mesh = scenes.with_materials(scenes.torus(3000))
+    W, H = 200, 150
+    ms = kernel.MultiScene(mesh, [0, 1])
+    assert ms.exchange == exchange
+    for frame_no in (0, 7):
+        fr = kernel.driver_frame(frame_no)
+        ms.transform(kernel.frame_matrix(fr, "obmat"))
+        assert torch.equal(ms.render_frame(fr, W, H, TAN_HALF), _single(mesh, fr, W, H)), frame_no
+    ms.close()
+
+
+def test_many_frames_on_the_same_worker_threads():
+    """The devices' host threads live as long as the set: many calls in a row, and a second set
+    beside the first."""
+    mesh = scenes.torus(1200)
+    W, H = 96, 80
+    a, b = kernel.MultiScene(mesh, [0, 0, 0]), kernel.MultiScene(mesh, [0, 0])
+    for frame_no in range(12):
+        fr = kernel.driver_frame(frame_no)
+        want = _single(mesh, fr, W, H)
+        for ms in (a, b):
+            ms.transform(kernel.frame_matrix(fr, "obmat"))
+            assert torch.equal(ms.render_frame(fr, W, H, TAN_HALF), want), frame_no
+    a.close()
+    b.close()
+
+
 def test_multi_more_parts_than_rows_and_errors():
     lib = _lib.load()
     mesh = scenes.torus(400)

@@ -63,6 +63,56 @@ def test_undecodable_maps_behave_like_a_failed_img_load(tmp_path, name):
     lib.rt_obj_free(h)
 
 
+def _png_chunk(kind, body):
+    import struct
+    import zlib
+    return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+
+
+def _huge_header_files():
+    """Small files whose headers declare enormous pictures: each must be refused before anything
+    is allocated for it (a texture file is untrusted input)."""
+    import struct
+    import zlib
+    png = (b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", struct.pack(">IIBBBBB", 32768, 32768, 16, 6, 0, 0, 0)) +
+           _png_chunk(b"IDAT", zlib.compress(bytes(64))) + _png_chunk(b"IEND", b""))
+    # the same size within the pixel cap's reach but far beyond what 80 bytes of IDAT can inflate to
+    png2 = (b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", struct.pack(">IIBBBBB", 8000, 8000, 8, 2, 0, 0, 0)) +
+            _png_chunk(b"IDAT", zlib.compress(bytes(64))) + _png_chunk(b"IEND", b""))
+    # baseline JPEG: SOI, a quantisation table, SOF0 declaring 65535 x 65535 YCbCr 4:2:0, Huffman
+    # tables, SOS and a few bytes of scan data
+    dqt = b"\xff\xdb" + struct.pack(">H", 67) + b"\x00" + bytes([1] * 64)
+    sof = b"\xff\xc0" + struct.pack(">HBHHB", 17, 8, 65535, 65535, 3) + bytes([1, 0x22, 0, 2, 0x11, 0, 3, 0x11, 0])
+    def dht(tc_th):
+        counts = [0] * 16
+        counts[0] = 2
+        return b"\xff\xc4" + struct.pack(">H", 2 + 1 + 16 + 2) + bytes([tc_th]) + bytes(counts) + bytes([0, 1])
+    sos = b"\xff\xda" + struct.pack(">HB", 12, 3) + bytes([1, 0, 2, 0, 3, 0]) + bytes([0, 63, 0])
+    jpg = b"\xff\xd8" + dqt + sof + dht(0x00) + dht(0x10) + sos + bytes(40) + b"\xff\xd9"
+    jpg_small = jpg.replace(struct.pack(">HH", 65535, 65535), struct.pack(">HH", 8000, 8000))
+    ppm = b"P6\n100000 100000\n255\n" + bytes(30)
+    bmp = bytearray(54 + 16)
+    bmp[0:2] = b"BM"
+    struct.pack_into("<I", bmp, 10, 54)
+    struct.pack_into("<iiHH", bmp, 18, 60000, 60000, 1, 24)
+    return {"huge.png": png, "huge2.png": png2, "huge.jpg": jpg, "huge2.jpg": jpg_small, "huge.ppm": ppm,
+            "huge.bmp": bytes(bmp)}
+
+
+@pytest.mark.parametrize("name", sorted(_huge_header_files()))
+def test_huge_headers_are_refused_without_allocating(tmp_path, name):
+    import resource
+    (tmp_path / name).write_bytes(_huge_header_files()[name])
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    lib, h = _load_with_maps(tmp_path, f"map_Kd {name}\n")
+    v = _lib.RtObjView()
+    assert lib.rt_obj_get(h, C.byref(v)) == 0
+    assert lib.rt_obj_num_textures(h) == 0 and v.map_Kd[0] == -1             # like a failed IMG_Load
+    lib.rt_obj_free(h)
+    # (ru_maxrss is in KiB: nothing like the gigabytes the headers ask for was ever touched)
+    assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < 512 * 1024
+
+
 @pytest.mark.gpu
 def test_png_textured_quad_against_the_oracle(tmp_path):
     import torch

@@ -51,6 +51,30 @@ def test_static_entry_matches_allocating_entry_twice():
     sc.close()
 
 
+def test_static_entry_after_rt_init_again():
+    """The static workspace is looked up by the scene's own device, not by whichever device the
+    most recent rt_init named: the same results after rt_init(0) has run once more."""
+    import torch
+
+    mesh = scenes.triangle_soup(1200, seed=4)
+    fr = kernel.driver_frame(2)
+    X, Y, Z = O.transform(mesh, kernel.frame_matrix(fr, "obmat"))
+    centre = np.array([X[1:].mean(), Y[1:].mean(), Z[1:].mean()])
+    sc = kernel.Scene(mesh)
+    sc.transform(kernel.frame_matrix(fr, "obmat"))
+    S, E = _rays(np.random.default_rng(5), centre, 2000)
+    before = sc.trace_rays(S, E, static=True)
+    _lib.check(_lib.load().rt_init(0), "rt_init")
+    after = sc.trace_rays(S, E, static=True)
+    plain = sc.trace_rays(S, E)
+    m = plain[0] >= 0
+    assert int(m.sum()) > 100
+    for a, b, c in zip(before, after, plain):
+        assert torch.equal(a[m], b[m]) and torch.equal(b[m], c[m])
+    assert torch.equal(before[0], plain[0])
+    sc.close()
+
+
 def test_static_entry_rejects_oversized_batches():
     import torch
 

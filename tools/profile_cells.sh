@@ -11,17 +11,17 @@ run pmc_tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA_RDREQ_sum
 run pmc_tcp --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_PENDING_STALL_CYCLES_sum
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
-root = sys.argv[1]
+root = sys.argv[1]; import os; PAT = os.environ.get("KPAT", "k_sweep_cells")
 for f in sorted(glob.glob(root + "/*/*/*_counter_collection.csv")):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for row in csv.DictReader(open(f)):
-        if "k_sweep_cells" in row["Kernel_Name"]:
+        if PAT in row["Kernel_Name"]:
             per[row["Dispatch_Id"]][row["Counter_Name"]] += float(row["Counter_Value"])
     print("==", f.split("/")[-3])
     for d in sorted(per, key=int)[-2:]:         # the profiled frame's two launches
         print("  dispatch", d, " ".join(f"{k}={v:.4e}" for k, v in sorted(per[d].items())))
 for f in sorted(glob.glob(root + "/pmc_issue/*/*_kernel_trace.csv")):
     for row in csv.DictReader(open(f)):
-        if "k_sweep_cells" in row["Kernel_Name"]:
+        if PAT in row["Kernel_Name"]:
             print("  trace", row["Dispatch_Id"], (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6, "ms")
 PY
