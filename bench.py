@@ -4,13 +4,21 @@
 One "step" = one full frame of the pixel loop (driver.c:126-193) over a synthetic scene that
 is already resident in HBM: per-frame vertex transform + sweep-buffer rebuild, primary
 closest-hit sweep, fp64 confirmation, shading epilogue with its shadow-ray sweeps, and -- for
-N > 1 -- the gather of the row bands to rank 0 over RCCL.  The image is sharded by
-contiguous row bands (strong scaling: the frame is fixed, each GPU holds the full mesh).
+N > 1 -- the gather of the rows to rank 0 over RCCL.  The image is sharded by interleaved
+16-row blocks (strong scaling: the frame is fixed, each GPU holds the full mesh); a frame
+sequence (teapot_seq_4k) is sharded by frames instead (weak scaling, no exchange).
 
 Prints ONE JSON line on rank 0.  `value` is whole-job Mrays/s (primary + shadow rays of the
-frame divided by the frame time); ray-triangle tests/s and the fp32 roofline fraction of
-the dominant kernel (the closest-hit sweep, timed with HIP events on its launch stream
-inside the library) ride along, as does a CPU-oracle baseline timed on this host.
+frame divided by the frame time).  Along ride: pairs decided per second and the roofline of the
+sweeps (timed with HIP events on their launch stream inside the library; a "test" of the
+pixel-grid and cell-lattice sweeps is a (ray, triangle) pair DECIDED -- most of them by a
+separable box test shared by a lane's lattice -- not a pair evaluated on its own), the general
+Moller-Trumbore sweep on the same rays (`roofline.general_mt`: every pair evaluated on its own
+in fp32 FMAs), and a CPU-oracle baseline timed on this host.
+
+--obj PATH renders a user-supplied Wavefront file (loaded by the library's own loader) instead
+of the workload's procedural mesh; a path that does not exist prints "asset not available" and
+keeps the stand-in.
 """
 from __future__ import annotations
 
@@ -48,6 +56,56 @@ def make_mesh(kind: str, tris: int):
     if kind == "torus":
         return scenes.torus(tris)
     return scenes.sphere(tris)
+
+
+def load_mesh(workload: str, obj_path: str | None):
+    """The mesh of a run: the user's .obj through the library's loader (rt_obj_load) when the
+    file exists, else the workload's procedural stand-in.  Returns (mesh for host-side use,
+    ObjFile or None, note)."""
+    kind, tris, _, _ = WORKLOADS[workload]
+    if obj_path:
+        if os.path.exists(obj_path):
+            from raytracer_amd import kernel
+            obj = kernel.ObjFile(obj_path)
+            return obj.mesh(), obj, f"{os.path.basename(obj_path)}: {obj.num_tris} triangles (rt_obj_load)"
+        print(f"bench.py: asset not available: {obj_path}; using the procedural stand-in "
+              f"({kind}, {tris} triangles)", file=sys.stderr)
+        return make_mesh(kind, tris), None, f"asset not available ({os.path.basename(obj_path)}): procedural stand-in"
+    return make_mesh(kind, tris), None, "procedural"
+
+
+def general_mt(sc, W: int, H: int, dev, hit_primary=None) -> dict:
+    """The frame's primary rays given as rays in general position (S, E) to rt_trace_rays: the
+    sweep that evaluates every (ray, triangle) pair on its own with the Moller-Trumbore
+    determinants in fp32 FMAs (rt_sweep.hip, moment form: 21 executed flop per pair), timed by
+    the library's HIP events around the launch."""
+    import ctypes as C
+    import torch
+    from raytracer_amd import _lib, kernel
+    ez = (W // 2) / TAN_HALF                                    # driver.c:133
+    xs = (torch.arange(W, device=dev, dtype=torch.float64) - W // 2).expand(H, W)
+    ys = (torch.arange(H, device=dev, dtype=torch.float64) - H // 2)[:, None].expand(H, W)
+    E = torch.stack([xs, ys, torch.full((H, W), ez, device=dev, dtype=torch.float64)], dim=-1).reshape(-1, 3).contiguous()
+    S = torch.zeros_like(E)
+    sc.trace_rays(S[:4096], E[:4096])                           # the kernel's first launch
+    kernel.profile_enable(True)
+    kernel.profile_reset()
+    hit, _, _ = sc.trace_rays(S, E)
+    prof = kernel.profile_get()
+    kernel.profile_enable(False)
+    form, tile, rpl, flop = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _lib.load().rt_sweep_config(C.byref(form), C.byref(tile), C.byref(rpl), C.byref(flop))
+    ms = prof.sweep_ms
+    rate = prof.sweep_tests / (ms * 1e-3) if ms > 0 else 0.0
+    achieved = rate * flop.value / 1e12
+    out = {"kernel": "k_sweep<closest hit> (rays in general position, every pair evaluated on its own)",
+           "rays": int(S.shape[0]), "ms": ms, "tests": float(prof.sweep_tests), "tests_per_s": rate,
+           "flop_per_test": flop.value, "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+           "frac": achieved / PEAK_FP32_TFLOPS, "target_50pct_fp32_flops_met": bool(achieved / PEAK_FP32_TFLOPS >= 0.5),
+           "rays_per_lane": rpl.value, "tile_tris": tile.value}
+    if hit_primary is not None:
+        out["hit_equals_pixel_grid_sweep"] = bool(torch.equal(hit.reshape(H, W), hit_primary))
+    return out
 
 
 def measured_traffic(workload: str, cfg: str) -> dict | None:
@@ -117,7 +175,7 @@ def mix_alone(name: str, tests_per_s: float) -> dict:
     return {}
 
 
-ROCPROF_DIR = "profiles/r02g_bench_soup1m_4k"     # tools/profile_bench.sh over this program's default run
+ROCPROF_DIR = "profiles/r03_bench_soup1m_4k"      # tools/profile_bench.sh over this program's default run
 
 
 def rocprof_avg_ms(workload: str, kernel_prefix: str) -> dict | None:
@@ -145,6 +203,11 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="soup1m_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--obj", default=None, metavar="PATH",
+                    help="a Wavefront .obj to render instead of the workload's procedural mesh (its .mtl and "
+                         "image maps are looked up beside it); a missing file keeps the stand-in")
+    ap.add_argument("--no-general-mt", action="store_true",
+                    help="skip the general Moller-Trumbore sweep of the frame's primary rays (roofline.general_mt)")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the gather even with one rank")
@@ -197,15 +260,16 @@ def main() -> None:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     kind, tris, W, H = WORKLOADS[args.workload]
-    mesh = make_mesh(kind, tris)
+    mesh, obj, mesh_note = load_mesh(args.workload, args.obj)
     sequence = args.workload.endswith("_seq_4k")
     frames = [kernel.driver_frame(k, 360) for k in range(360)] if sequence else [kernel.driver_frame(0)]
     obmats = [kernel.frame_matrix(f, "obmat") for f in frames]
     frame = frames[0]
     step_no = [0]
     profiled = [False]        # the profiled frame of a --single-process run goes through the plain scene
-    sc = kernel.Scene(mesh, device=local_rank)
-    ms = kernel.MultiScene(mesh, devices) if single else None
+    gather_ms = [None]        # exchange + placement of the profiled frame (host clock around it, devices idle before)
+    sc = kernel.Scene(obj if obj is not None else mesh, device=local_rank)
+    ms = kernel.MultiScene(obj if obj is not None else mesh, devices) if single else None
     # A frame sequence is split by frames: rank r renders frames r, r + world, ... whole, and
     # nothing is exchanged (driver.c:196-199 writes one picture per frame; so would every rank).
     frame_parallel = sequence and world > 1
@@ -230,6 +294,11 @@ def main() -> None:
         sc.transform(obmats[k])                   # driver.c:110 on the device-resident mesh
         sc.render_rows(frames[k], W, H, TAN_HALF, want=("hit", "rgb8"), rows_set=my_rows,
                        out={"hit": out["hit"], "rgb8": out["rgb8"][:rows]})
+        timing_gather = profiled[0] and use_dist and not frame_parallel
+        if timing_gather:
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_g = time.perf_counter()
         if frame_parallel:
             sc.place_rows(out["rgb8"], W, H, screen=screen, rows_set=my_rows)
         elif use_dist:
@@ -248,6 +317,9 @@ def main() -> None:
                     sc.place_rows(gathered[r], W, H, screen=screen, rows_set=parallel.part_rows(H, world, r))
         else:
             sc.place_rows(out["rgb8"], W, H, screen=screen, rows_set=my_rows)
+        if timing_gather:
+            torch.cuda.synchronize()
+            gather_ms[0] = (time.perf_counter() - t_g) * 1e3
 
     def fence():
         torch.cuda.synchronize()
@@ -285,6 +357,8 @@ def main() -> None:
                                      C.byref(f_shadow), C.byref(chunks))
     mix = [C.c_int() for _ in range(5)]
     _lib.load().rt_raster_sweep_mix(*[C.byref(m) for m in mix])
+    regular = C.c_int()
+    _lib.load().rt_raster_sweep_form(C.byref(regular))
 
     # The same steps once more with the library's tile culling on (off by default: the headline
     # is the all-pairs sweep).  Every wave still visits every triangle, but tests a tile's
@@ -333,14 +407,75 @@ def main() -> None:
         tests_per_s_launch = tests_per_launch / (sweep_ms_avg * 1e-3) if sweep_ms_avg > 0 else 0.0
         achieved = tests_per_s_launch * f_exec / 1e12
         traffic = measured_traffic(args.workload, f"raster-tile{tile.value}-ppl{ppl.value}-chunks{chunks.value}") if world == 1 else None
-        rp = rocprof_avg_ms(args.workload, f"k_sweep_raster<{ppl.value}, false>") if world == 1 else None
-        # the any-hit sweeps of the shadow rays: a third of the frame
+        ms_step = wall / steps * 1e3
+        raster_name = f"k_sweep_raster<{ppl.value}, false, {'true' if regular.value else 'false'}>"
+        rp = rocprof_avg_ms(args.workload, raster_name) if world == 1 else None
+        # the any-hit sweeps of the shadow rays
         sh_ms, sh_tests = prof.shadow_ms, float(prof.shadow_tests)
         sh_rate = sh_tests / (sh_ms * 1e-3) if sh_ms > 0 else 0.0
-        # hot loop of the widest any-hit kernel (u half of the bounding-square test): a subtraction per
-        # ray, a three-way minimum per two, one compare per triangle (25 VALU instructions per 16 pairs)
-        sh_instr = (spl.value + spl.value // 2 + 1) / spl.value
-        rp_sh = rocprof_avg_ms(args.workload, f"k_sweep_apex<{spl.value}, false>") if world == 1 else None
+        if prof.cell_launches > 0:
+            # sweeps over lattices of direction cells: the hot loop executes one separable test per
+            # (cell, triangle) pair -- an addition per column and per row of a lane's lattice, a
+            # three-way minimum per two of either, two compares -- and the rare path tests the rays
+            # of a passing cell one by one
+            cpl = int(prof.cells_per_lane)
+            c_rows = {2048: 32, 512: 16, 128: 8, 32: 4, 8: 2}[cpl]
+            c_cols = cpl // c_rows
+            c_instr = (c_cols + c_rows + c_cols // 2 + c_rows // 2 + 2) / cpl
+            c_flop = (c_cols + c_rows) / cpl
+            c_rate = prof.cell_pairs / (prof.cell_ms * 1e-3) if prof.cell_ms > 0 else 0.0
+            rp_sh = rocprof_avg_ms(args.workload, f"k_sweep_cells<{cpl}>") if world == 1 else None
+            anyhit = {
+                "kernel": f"k_sweep_cells<{cpl}> (shadow rays, any hit: every cell of a lattice of directions against "
+                          "every triangle, the rays of a passing cell one by one)",
+                "ms_per_frame": sh_ms, "share_of_step": sh_ms / ms_step, "launches_per_frame": int(prof.shadow_launches),
+                "lattice_launches": int(prof.cell_launches), "ms_in_lattice_launches": prof.cell_ms,
+                "rays_swept": float(prof.cell_rays), "cell_pairs_per_frame": float(prof.cell_pairs),
+                "cell_pairs_per_s": c_rate, "ray_pairs_one_by_one_per_frame": float(prof.cell_ray_pairs),
+                "row_lookups_per_frame": float(prof.cell_lookups),
+                "tests_per_frame": sh_tests, "tests_per_s": sh_rate,
+                "test": "a (ray, triangle) pair decided: every listed ray against every triangle, most pairs through "
+                        "their cell's test",
+                "flop_per_cell_pair": c_flop, "achieved": c_rate * c_flop / 1e12, "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s", "frac": c_rate * c_flop / 1e12 / PEAK_FP32_TFLOPS,
+                "rocprof": rp_sh,
+                "valu_issue": {"instr_per_cell_pair": c_instr,
+                               "per_lane_and_triangle": {"cells": cpl, "add": c_cols + c_rows,
+                                                         "logic": c_cols // 2 + c_rows // 2, "compare": 2},
+                               "achieved": c_rate * c_instr / 1e12, "peak": PEAK_VALU_TINSTR, "unit": "T lane-instr/s",
+                               "frac": c_rate * c_instr / 1e12 / PEAK_VALU_TINSTR,
+                               **mix_alone(f"raster{cpl}_box", c_rate)},
+                "cells_per_lane": cpl,
+            }
+        else:
+            # hot loop of the widest ray-by-ray kernel (u half of the bounding-square test): a subtraction
+            # per ray, a three-way minimum per two, one compare per triangle (25 VALU instructions per 16 pairs)
+            sh_instr = (spl.value + spl.value // 2 + 1) / spl.value
+            rp_sh = rocprof_avg_ms(args.workload, f"k_sweep_apex<{spl.value}, false>") if world == 1 else None
+            anyhit = {
+                "kernel": f"k_sweep_apex<{spl.value}, false> (shadow rays, any hit, ray by ray)",
+                "ms_per_frame": sh_ms, "share_of_step": sh_ms / ms_step, "launches_per_frame": int(prof.shadow_launches),
+                "tests_per_frame": sh_tests, "tests_per_s": sh_rate,
+                "flop_per_test": f_shadow.value,
+                "achieved": sh_rate * f_shadow.value / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": sh_rate * f_shadow.value / 1e12 / PEAK_FP32_TFLOPS,
+                "rocprof": rp_sh,
+                "valu_issue": {"instr_per_test": sh_instr, "achieved": sh_rate * sh_instr / 1e12,
+                               "peak": PEAK_VALU_TINSTR, "unit": "T lane-instr/s",
+                               "frac": sh_rate * sh_instr / 1e12 / PEAK_VALU_TINSTR,
+                               **mix_alone(f"apex{spl.value}_strip", sh_rate)},
+                "rays_per_lane": spl.value,
+            }
+        primary_ms = prof.sweep_ms
+        comm = {"backend": (dist.get_backend() if use_dist else None),
+                "world_size": (dist.get_world_size() if use_dist else 1),
+                "exchange": ("none: every rank renders whole frames" if frame_parallel else
+                             ("gather of the 8-bit rows to rank 0" if use_dist else "none: one process, one device")),
+                "gather_ms": gather_ms[0],
+                "gather_ms_is": "exchange + placement of the profiled frame on rank 0, host clock, all ranks idle before it"}
+        if single:
+            comm = {"backend": ms.exchange, "world_size": 1, "devices": devices,
+                    "exchange": "rt_render_frame_multi: rows to the first device inside the call", "gather_ms": None}
         res = {
             "metric": "Mrays/s and ray-tri tests/s (% fp32 peak) at 1/2/4/8 MI355X vs host-CPU ref",
             "value": (rays_p + rays_s) / (wall / steps) / 1e6,
@@ -352,7 +487,7 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": args.workload, "mesh": mesh.name, "triangles": mesh.num_tris,
+            "config": {"workload": args.workload, "mesh": mesh.name, "mesh_source": mesh_note, "triangles": mesh.num_tris,
                        "width": W, "height": H, "lights": frame.num_lights,
                        "sharding": f"{world} ranks, one whole frame each per step (frames rank, rank + {world}, ...), no exchange"
                        if frame_parallel else (f"{world} interleaved row parts (16-row blocks), "
@@ -364,6 +499,11 @@ def main() -> None:
             "primary_mrays_per_s": rays_p / (wall / steps) / 1e6,
             "rays_per_frame": {"primary": rays_p, "shadow": rays_s},
             "tests_per_s": tests / (wall / steps),
+            "tests_per_s_counts": "(ray, triangle) pairs decided per second of the frame: every primary ray and every "
+                                  "swept shadow ray against every triangle; the sweeps decide most pairs through a box "
+                                  "test shared by a lane's lattice, not one by one (roofline.general_mt is the sweep "
+                                  "that evaluates each pair on its own)",
+            "comm": comm,
             "hit_fraction_rank0": hit_frac,
             "fp64_confirmations_per_frame": tsum[8].item(),
             "overflow_rays_per_frame": tsum[9].item(),
@@ -383,7 +523,9 @@ def main() -> None:
             # of the image's own pixels: the lanes of a wave that reaches beyond the right edge
             # execute their tests too, uncounted.
             "roofline": {
-                "bound": "valu-fp32", "kernel": f"k_sweep_raster<{ppl.value}, false> (primary rays, closest hit, all pairs)",
+                "bound": "valu-fp32", "kernel": f"{raster_name} (primary rays, closest hit, all pairs)",
+                "dominant_by_time": "this kernel" if primary_ms >= sh_ms else "anyhit (below)",
+                "share_of_step": primary_ms / ms_step,
                 "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS,
                 "target_50pct_fp32_flops_met": bool(achieved / PEAK_FP32_TFLOPS >= 0.5),
@@ -407,22 +549,18 @@ def main() -> None:
                 "sweep_kernel": {"tile_tris": tile.value, "pixels_per_lane": ppl.value,
                                  "triangle_chunks": chunks.value},
                 # second kernel: the any-hit sweeps (rank 0, all launches of the profiled frame)
-                "anyhit": {
-                    "kernel": f"k_sweep_apex<{spl.value}, false> (shadow rays, any hit, all pairs)",
-                    "ms_per_frame": sh_ms, "launches_per_frame": int(prof.shadow_launches),
-                    "tests_per_frame": sh_tests, "tests_per_s": sh_rate,
-                    "flop_per_test": f_shadow.value,
-                    "achieved": sh_rate * f_shadow.value / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": sh_rate * f_shadow.value / 1e12 / PEAK_FP32_TFLOPS,
-                    "rocprof": rp_sh,
-                    "valu_issue": {"instr_per_test": sh_instr, "achieved": sh_rate * sh_instr / 1e12,
-                                   "peak": PEAK_VALU_TINSTR, "unit": "T lane-instr/s",
-                                   "frac": sh_rate * sh_instr / 1e12 / PEAK_VALU_TINSTR,
-                                   **mix_alone(f"apex{spl.value}_strip", sh_rate)},
-                    "rays_per_lane": spl.value,
-                },
+                "anyhit": anyhit,
             },
         }
+        if world == 1 and not single and not sequence and not args.no_general_mt:
+            # the literal Moller-Trumbore kernel on the same rays, and on the 100 k-triangle mesh
+            res["roofline"]["general_mt"] = general_mt(sc, W, H, dev, out["hit"])
+            if args.workload == "soup1m_4k" and obj is None:
+                k2, t2, _, _ = WORKLOADS["mesh100k_4k"]
+                sc2 = kernel.Scene(make_mesh(k2, t2), device=local_rank)
+                sc2.transform(obmats[0])
+                res["roofline"]["general_mt_mesh100k_4k"] = general_mt(sc2, W, H, dev)
+                sc2.close()
         if culling_was_on:
             res["config"]["tile_culling"] = "on for the whole run (RT_AMD_CULL): the figures above are not the all-pairs sweep's"
         else:

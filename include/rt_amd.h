@@ -288,6 +288,11 @@ int rt_apex_sweep_config(int* tile_tris, int* primary_pixels_per_lane,
  * distance from the centre of a triangle's bounding box from one pixel of the lane to the
  * next, and minima that collect them. */
 int rt_raster_sweep_mix(int* pixels_per_lane, int* fma, int* add, int* logic, int* compare);
+/* Whether the most recent primary sweep ran the form of the kernel that steps from row to row by a
+ * constant (every aligned group of 16 rows of the call's row set consecutive image rows: whole
+ * bands, and interleaved parts whose block height is a multiple of 16) or the one that holds a
+ * coordinate per row. */
+int rt_raster_sweep_form(int* regular_rows);
 /* Tile culling (off by default).  The first test of every (ray, triangle) pair is the ray against
  * the bounding box of the triangle's projection (on the image plane for primary rays, on the
  * plane of the dominant axis through the light for shadow rays).  With culling on, every

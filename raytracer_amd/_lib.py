@@ -136,6 +136,7 @@ SIGNATURES = {
     "rt_apex_sweep_config": (C.c_int, [c_int_p, c_int_p, C.POINTER(C.c_double), c_int_p,
                                        C.POINTER(C.c_double), c_int_p]),
     "rt_raster_sweep_mix": (C.c_int, [c_int_p] * 5),
+    "rt_raster_sweep_form": (C.c_int, [c_int_p]),
     "rt_set_tile_culling": (C.c_int, [C.c_int]),
     "rt_get_tile_culling": (C.c_int, []),
     "rt_profile_enable": (C.c_int, [C.c_int]),

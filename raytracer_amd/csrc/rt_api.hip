@@ -146,6 +146,12 @@ extern "C" int rt_raster_sweep_mix(int* pixels_per_lane, int* fma, int* add, int
     return RT_OK;
 }
 
+extern "C" int rt_raster_sweep_form(int* regular_rows)
+{
+    if (regular_rows) *regular_rows = rt_g().last_raster_regular.load();
+    return RT_OK;
+}
+
 extern "C" int rt_profile_enable(int on) { rt_g().profiling = on != 0; return RT_OK; }
 
 bool rt_tile_culling()
@@ -697,6 +703,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     const uint64_t tests = (uint64_t)npix * (uint64_t)sc->num_tris_padded;
     g.last_raster_rpl.store(rpl, std::memory_order_relaxed);
     g.last_raster_chunks.store(chunks, std::memory_order_relaxed);
+    g.last_raster_regular.store(regular ? 1 : 0, std::memory_order_relaxed);
     RT_TRY(timed_sweep([&] { return rt_launch_sweep_raster(a, st); }, false, tests, nullptr));
     // (queued by the host after the sweep, so that the sweep is not kept waiting for a dozen small
     // launches; on the device the side stream only waits for what preceded the sweep)

@@ -200,6 +200,7 @@ struct RtGlobal {
     int tile_culling = -1;                  // rt_set_tile_culling; -1: not set, RT_AMD_CULL decides
     std::atomic<int> last_raster_rpl{0};    // pixels per lane of the most recent primary sweep
     std::atomic<int> last_raster_chunks{0}; // and its triangle chunks
+    std::atomic<int> last_raster_regular{0};    // and whether it ran the regular-row form
     rt_profile prof{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };

@@ -42,6 +42,12 @@
 // proportional to the index of its first occluder instead of the triangle count.
 #include "rt_sweep_common.h"
 
+#ifndef RT_SWEEP_WAVES
+#define RT_SWEEP_WAVES 5    // waves per SIMD the kernel must fit (96 registers: the ray set-up and the rare path
+                            // spill, the hot loop does not; measured on 8.3 M rays x 100 k triangles: 217 ms
+                            // at three waves (150 registers), 201 at four, 198 at five)
+#endif
+
 namespace {
 
 using namespace rt_sweep;
@@ -51,7 +57,7 @@ struct Ray {
     float dx, dy, dz;   // unit direction
 };
 
-// planes: 0 = (nn, 2eu)   1 = (g = e2 x v0, eu)   2 = (e2, et)   3 = (e1, k = v0.nn)
+// planes: 0 = (nn, 2eu)   1 = (-g, eu), g = e2 x v0   2 = (e2, et)   3 = (e1, k = v0.nn)
 //         4 = (h = e1 x v0, 0)                                          [3, 4: u slab only]
 struct Tri { float4 NN, G, E2; };
 __device__ __forceinline__ Tri load_tri(const float4* p) { return {p[0], p[RT_TILE], p[2 * RT_TILE]}; }
@@ -60,13 +66,14 @@ __device__ __forceinline__ Tri load_tri(const float4* p) { return {p[0], p[RT_TI
 __device__ __forceinline__ bool in_u_slab(const Ray& r, const Tri& q, float& d, float& a, float& w1)
 {
     d = dot3(r.dx, r.dy, r.dz, q.NN.x, q.NN.y, q.NN.z);
-    // U = e2.M - D.g, one six-term FMA chain
+    // U = e2.M - D.g, one six-term FMA chain (the plane holds -g: a negated operand would cost every
+    // one of these three the longer encoding, which issues more slowly)
     float U = r.mx * q.E2.x;
     U = __builtin_fmaf(r.my, q.E2.y, U);
     U = __builtin_fmaf(r.mz, q.E2.z, U);
-    U = __builtin_fmaf(-r.dx, q.G.x, U);
-    U = __builtin_fmaf(-r.dy, q.G.y, U);
-    U = __builtin_fmaf(-r.dz, q.G.z, U);
+    U = __builtin_fmaf(r.dx, q.G.x, U);
+    U = __builtin_fmaf(r.dy, q.G.y, U);
+    U = __builtin_fmaf(r.dz, q.G.z, U);
     a = U * d;
     w1 = __builtin_fmaf(d, d, -a);
     return __builtin_fmaf(q.NN.w, __builtin_fabsf(d), __builtin_fminf(a, w1)) > 0.0f;
@@ -104,7 +111,7 @@ __device__ __forceinline__ void finish_pair(Book& bk, const Ray& r, int32_t* __r
 enum { MODE_RAYS_LINEAR = 1, MODE_RAYS_INDEXED = 3 };
 
 template <int MODE, bool ANYHIT>
-__global__ void __launch_bounds__(RT_WG, RT_MIN_WAVES) k_sweep(const SweepArgs A)
+__global__ void __launch_bounds__(RT_WG, RT_SWEEP_WAVES) k_sweep(const SweepArgs A)
 {
     // double-buffered planes of one tile
     __shared__ float4 tile[2][RT_PLANES][RT_TILE];

@@ -97,7 +97,7 @@ k_pack(const double* __restrict__ x, const double* __restrict__ y, const double*
     const double hx = e1y * az - e1z * ay, hy = e1z * ax - e1x * az, hz = e1x * ay - e1y * ax;
     const double k = ax * nx + ay * ny + az * nz;
     *p[0] = make_float4((float)nx, (float)ny, (float)nz, eu2);
-    *p[1] = make_float4((float)gx, (float)gy, (float)gz, eu);
+    *p[1] = make_float4((float)-gx, (float)-gy, (float)-gz, eu);       // (-g: see in_u_slab, rt_sweep.hip)
     *p[2] = make_float4((float)e2x, (float)e2y, (float)e2z, et);
     *p[3] = make_float4((float)e1x, (float)e1y, (float)e1z, (float)k);
     *p[4] = make_float4((float)hx, (float)hy, (float)hz, 0.0f);

@@ -8,6 +8,7 @@ only to own device memory for outputs.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -134,6 +135,65 @@ def rows_image_rows(r: RtRows) -> np.ndarray:
 
 # ------------------------------------------------------------------ batched API
 
+class ObjFile:
+    """A Wavefront .obj loaded by the library (rt_obj_load: obj_reader.c:628-726 semantics, quads
+    split, centre + scale, page-locked SoA when a GPU is present).  `mesh()` is a host copy of
+    its arrays for code that wants to look at them (the CPU oracle, triangle counts)."""
+
+    def __init__(self, path: str):
+        self.lib = _lib.load()
+        self.path = path
+        h = C.c_void_p()
+        check(self.lib.rt_obj_load(os.fsencode(path), C.byref(h)), "rt_obj_load")
+        self.h = h
+        self.view = _lib.RtObjView()
+        check(self.lib.rt_obj_get(self.h, C.byref(self.view)), "rt_obj_get")
+
+    @property
+    def num_tris(self) -> int:
+        return int(self.view.num_tris)
+
+    def mesh(self) -> Mesh:
+        v = self.view
+
+        def d(ptr, n):
+            return np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0)
+
+        def i(ptr, n):
+            return np.ctypeslib.as_array(ptr, shape=(n,)).astype(np.int32) if n else np.zeros(0, np.int32)
+
+        nt, nm = v.num_tris, v.num_mats
+        textures = []
+        for k in range(self.lib.rt_obj_num_textures(self.h)):
+            w, hh, px = C.c_int(), C.c_int(), C.c_void_p()
+            check(self.lib.rt_obj_texture(self.h, k, C.byref(w), C.byref(hh), C.byref(px)), "rt_obj_texture")
+            buf = (C.c_uint8 * (w.value * hh.value * 3)).from_address(px.value)
+            textures.append(np.frombuffer(buf, np.uint8).reshape(hh.value, w.value, 3).copy())
+        has_vt = v.num_vt > 0
+        return Mesh(x=d(v.x, v.num_v + 1), y=d(v.y, v.num_v + 1), z=d(v.z, v.num_v + 1),
+                    xn=d(v.xn, v.num_vn + 1), yn=d(v.yn, v.num_vn + 1), zn=d(v.zn, v.num_vn + 1),
+                    u=d(v.u, v.num_vt + 1), v=d(v.v, v.num_vt + 1),
+                    A=i(v.A, nt), B=i(v.B, nt), C=i(v.C, nt), An=i(v.An, nt), Bn=i(v.Bn, nt), Cn=i(v.Cn, nt),
+                    At=i(v.At, nt) if has_vt else None, Bt=i(v.Bt, nt) if has_vt else None,
+                    Ct=i(v.Ct, nt) if has_vt else None, mtl=i(v.mtl, nt),
+                    Ka=d(v.Ka, 3 * nm).reshape(nm, 3), Kd=d(v.Kd, 3 * nm).reshape(nm, 3),
+                    Ks=d(v.Ks, 3 * nm).reshape(nm, 3),
+                    map_Ka=i(v.map_Ka, nm) if nm else None, map_Kd=i(v.map_Kd, nm) if nm else None,
+                    map_Ks=i(v.map_Ks, nm) if nm else None, textures=textures,
+                    name=f"{os.path.basename(self.path)} ({nt} triangles)")
+
+    def close(self):
+        if self.h:
+            self.lib.rt_obj_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Scene:
     """Device-resident mesh + the batched trace/render calls (include/rt_amd.h, group 2)."""
 
@@ -148,8 +208,14 @@ class Scene:
         check(self.lib.rt_scene_create(C.byref(h)), "rt_scene_create")
         self.h = h
         self.mesh = None
-        if mesh is not None:
+        if isinstance(mesh, ObjFile):
+            self.set_obj(mesh)
+        elif mesh is not None:
             self.set_mesh(mesh)
+
+    def set_obj(self, obj: "ObjFile") -> None:
+        """The loaded file's arrays straight from the library's own (page-locked) buffers."""
+        check(self.lib.rt_scene_set_obj(self.h, obj.h), "rt_scene_set_obj")
 
     @classmethod
     def adopt(cls, handle, device: int = 0) -> "Scene":
@@ -323,6 +389,9 @@ class MultiScene:
         check(self.lib.rt_multi_create(C.byref(h), len(devs), _ip(devs)), "rt_multi_create")
         self.h = h
         self.devices = [int(d) for d in devs]
+        if isinstance(mesh, ObjFile):
+            check(self.lib.rt_multi_set_obj(self.h, mesh.h), "rt_multi_set_obj")
+            return
         errors = []
 
         @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
