@@ -316,7 +316,9 @@ constexpr int RT_RASTER_MAX_CHUNKS = 2048;
 // and how the four waves of a workgroup are laid out: waves_x (4, 2 or 1) side by side, the rest
 // below, i.e. workgroup tiles of (waves_x * RT_RASTER_COLS * pixels_per_lane) x (64 / waves_x) pixels;
 // or waves_x = 0: the wave-sized pixel blocks of the band, numbered row by row, four consecutive
-// ones to a workgroup (at most three idle waves in the whole launch; the launcher's own choice)
+// ones to a workgroup (at most three idle waves in the whole launch; the launcher's choice for the
+// form with a coordinate per row); or waves_x = -1: a workgroup per wave-sized block, its four waves
+// sweeping a quarter of every tile of triangles each (the launcher's choice for the regular-row form)
 // regular: every aligned group of 16 local rows is 16 consecutive image rows (rt_rows_regular)
 void rt_raster_shape(int W, int rows, int tiles, bool regular, int* pixels_per_lane, int* chunks, int* waves_x);
 inline bool rt_rows_regular(const RowMap& m) { return m.parts == 1 || m.block % 16 == 0; }
@@ -330,6 +332,10 @@ inline long rt_raster_pairs(int W, int rows, int pixels_per_lane, long tris)
 // workgroup tiles that shape needs to cover W x rows pixels
 inline long rt_raster_tiles(int W, int rows, int pixels_per_lane, int waves_x)
 {
+    if (waves_x < 0) {          // a workgroup per wave-sized block
+        const int ww = rt_raster_wave_cols(pixels_per_lane), wh = rt_raster_wave_rows(pixels_per_lane);
+        return (long)((W + ww - 1) / ww) * ((rows + wh - 1) / wh);
+    }
     if (waves_x == 0) {
         const int ww = rt_raster_wave_cols(pixels_per_lane), wh = rt_raster_wave_rows(pixels_per_lane);
         return ((long)((W + ww - 1) / ww) * ((rows + wh - 1) / wh) + 3) / 4;

@@ -360,7 +360,7 @@ k_sweep_raster(const SweepArgs A)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: triangle numbers stay out of the vector unit)
 
     // wave = (COLS R) x (64 / COLS) pixels; workgroup = its four waves side by side ((16 R) x 16
     // pixels), two by two or stacked.  (The squarer a wave's pixels, the fewer triangles have one
@@ -375,8 +375,18 @@ k_sweep_raster(const SweepArgs A)
     // the image's right and bottom edges)
     // ... or, waves_x = 0, the wave-sized blocks of the band numbered row by row and dealt four
     // to a workgroup: no idle waves but in the last workgroup
+    // ... or, waves_x = -1, one wave-sized block per workgroup: its four waves own the same pixels
+    // and sweep a quarter of every tile of triangles each (they share the pixels' state through
+    // the same atomics as the workgroups of different triangle chunks do).  No idle waves at all,
+    // which matters for a row part of a few hundred rows: 270 rows are five blocks of 64.
+    const bool shared_block = A.waves_x < 0;
     int wave_x0, wave_y0;
-    if (A.waves_x == 0) {
+    if (shared_block) {
+        const int cols = (A.W + WW - 1) / WW;
+        const int w = blockIdx.x, wy = w / cols;
+        wave_x0 = (w - wy * cols) * WW;
+        wave_y0 = wy * WH;
+    } else if (A.waves_x == 0) {
         const int cols = (A.W + WW - 1) / WW;
         const int w = blockIdx.x * 4 + wave, wy = w / cols;
         wave_x0 = (w - wy * cols) * WW;
@@ -477,15 +487,17 @@ k_sweep_raster(const SweepArgs A)
         } else {
             // LDS reads are issued one triangle ahead by hand (the rare path splits the body into
             // basic blocks, which keeps the compiler from hoisting them)
+            // this wave's triangles of a tile: all of them, or its quarter
+            const int q0 = shared_block ? wave * (RT_TILE / 4) : 0, qn = shared_block ? RT_TILE / 4 : RT_TILE;
             for (int sub = 0; wave_on && sub < count; ++sub) {
                 // (the address in a vector register the compiler cannot see through, advanced once
                 // per kRasterUnroll triangles, the reads at immediate offsets: formed in scalar
                 // registers it would be copied to a vector register before every read; the last
-                // read of a tile touches the entry behind it and is not used)
-                unsigned box_at = lds_address(base + sub * RT_TILE);
+                // read of a tile or quarter touches the entry behind it and is not used)
+                unsigned box_at = lds_address(base + sub * RT_TILE + q0);
                 asm volatile("" : "+v"(box_at));
                 float4 next = lds_read_float4(box_at);
-                for (int j4 = 0; j4 < RT_TILE; j4 += kRasterUnroll) {
+                for (int j4 = q0; j4 < q0 + qn; j4 += kRasterUnroll) {
 #pragma unroll
                     for (int k = 0; k < kRasterUnroll; ++k) {
                         const float4 box = next;
@@ -506,7 +518,8 @@ k_sweep_raster(const SweepArgs A)
 
     // pairs tested one by one: all of them, or with tile culling those of the surviving triangles
     if (A.tests && lane == 0 && wave_on)
-        atomicAdd(A.tests, (CULL ? (unsigned long long)kept : tiles_done * (unsigned long long)RT_TILE) * (64 * R));
+        atomicAdd(A.tests, (CULL ? (unsigned long long)kept
+                                 : tiles_done * (unsigned long long)(shared_block ? RT_TILE / 4 : RT_TILE)) * (64 * R));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1090,7 +1103,7 @@ int rt_device_cus()
 // every kernel shape on small inputs).
 void rt_raster_shape(int W, int rows, int tiles, bool regular, int* pixels_per_lane, int* chunks, int* waves_x)
 {
-    const long slots = 5L * rt_device_cus();           // resident workgroups
+    const long slots = (regular ? 8L : 5L) * rt_device_cus();      // resident workgroups
     int max_chunks = tiles;                            // a chunk may be a single tile
     if (max_chunks < 1) max_chunks = 1;
     // (the chunks of a pixel share its candidate list, so their number costs no memory)
@@ -1104,7 +1117,8 @@ void rt_raster_shape(int W, int rows, int tiles, bool regular, int* pixels_per_l
     // the row-by-row dealing of the waves leaves at most three of them idle in the whole launch
     // (an idle wave does no arithmetic but keeps its slot on a SIMD whose issue rate needs all
     // eight); the rectangular layouts remain for forced shapes
-    auto best_layout = [&](int) { return 0; };
+    // ... and the regular-row form gives every wave-sized block a workgroup of its own (no idle wave at all)
+    auto best_layout = [&](int) { return regular && !rt_tile_culling() ? -1 : 0; };
     // most pixels per lane this call can use: 4096 (64 rows) only in the regular-row form, and not
     // with tile culling
     const int rpl_max = regular && !rt_tile_culling() ? RT_RASTER_RPL_REGULAR : RT_RASTER_RPL;
@@ -1117,7 +1131,7 @@ void rt_raster_shape(int W, int rows, int tiles, bool regular, int* pixels_per_l
             fr <= rpl_max) {
             *pixels_per_lane = fr;
             *chunks = fc;
-            *waves_x = (n == 3 && (fw == 0 || fw == 1 || fw == 2 || fw == 4)) ? fw : best_layout(fr);
+            *waves_x = (n == 3 && (fw == -1 || fw == 0 || fw == 1 || fw == 2 || fw == 4)) ? fw : best_layout(fr);
             return;
         }
     }

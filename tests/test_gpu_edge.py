@@ -459,7 +459,7 @@ def test_triangles_whose_plane_contains_a_light():
 @pytest.mark.parametrize("shape", ["16,1", "16,3", "8,2", "4,1", "2,5", "1,1", "16,2,2", "16,1,1", "8,3,1", "4,2,2",
                                    "32,1", "32,2,2", "32,3,1", "64,1", "64,2,1", "64,3,4", "128,1", "128,3,2", "128,2,1",
                                    "256,1", "256,2,4", "256,5,1", "512,1", "512,3,0", "1024,1", "1024,2,0", "1024,4,1", "2048,1", "2048,3,0", "2048,2,1",
-                                   "4096,1", "4096,3,0", "4096,2,1"])
+                                   "4096,1", "4096,3,0", "4096,2,1", "4096,3,-1", "2048,2,-1", "256,2,-1", "16,3,-1", "1,2,-1"])
 @pytest.mark.parametrize("W,H", [(500, 20), (37, 19), (200, 150)])
 @pytest.mark.parametrize("regular", [None, "0"])
 def test_every_shape_of_the_pixel_grid_sweep(shape, W, H, monkeypatch, regular):
