@@ -388,9 +388,13 @@ def main() -> None:
                          dtype=torch.float64, device=dev)
     tmax = stats.clone()
     tsum = stats.clone()
+    # every rank's own clock and frame count (a sequence is split by frames: rank r renders frames r, r + world, ...)
+    mine = torch.tensor([dt, float(args.steps)], dtype=torch.float64, device=dev)
+    per_rank = [mine.clone() for _ in range(world)] if use_dist else [mine]
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dist.all_gather(per_rank, mine)
     if rank == 0:
         wall = tmax[0].item()
         steps = args.steps
@@ -496,6 +500,11 @@ def main() -> None:
                                           "(one host thread per device, rows to the first device over RCCL send/recv; peer copies where a device is named twice)"
                                           if single else "single GPU")},
             "frames_per_s": steps * (world if frame_parallel else 1) / wall,
+            # whole frames each rank rendered in the timed region and its own seconds (a sequence under
+            # several ranks: the frame rate above is the sum of the ranks' frames over the slowest rank's clock)
+            "frames": {"per_rank": [int(t[1].item()) for t in per_rank] if frame_parallel else [steps] * (world if use_dist else 1),
+                       "whole_frames_per_rank": bool(frame_parallel or world == 1),
+                       "seconds_per_rank": [t[0].item() for t in per_rank]},
             "primary_mrays_per_s": rays_p / (wall / steps) / 1e6,
             "rays_per_frame": {"primary": rays_p, "shadow": rays_s},
             "tests_per_s": tests / (wall / steps),

@@ -8,36 +8,38 @@
 // vanishes when the triangle is expressed relative to the shared point P, and the three
 // determinants become plain dot products of the ray direction with per-triangle vectors
 // (k_pack_apex, rt_transform.hip):   U = D.p   W' = det - U = D.q   V = D.h   det = D.nn.
-// Every (ray, triangle) pair first meets a cheap conservative test (the u slab 0 <= u <= 1 for
-// the pixel grid, a bounding square for the shadow rays); the rare path behind it finishes the
-// inside test (U, V, det, the three edges, the ray parameter) and appends survivors to the ray's
-// candidate list; the fp64 pass of rt_exact.hip then decides with the reference's exact
-// arithmetic.
+// Every (ray, triangle) pair first meets a cheap conservative test -- the triangle's bounding box
+// on a plane in front of P: the image plane for the pixel grid, the plane of the rays' dominant
+// axis for the shadow rays -- and the rare path behind it finishes the inside test (U, V, det,
+// the three edges, the ray parameter) and appends survivors to the ray's candidate list; the
+// fp64 pass of rt_exact.hip then decides with the reference's exact arithmetic.
 //
-//   k_sweep_apex    any-hit, for the shadow rays of up to four lights.  Directions are scaled to
-//                   a unit dominant component, D' = D / D_k (rays binned by that axis,
-//                   k_bin_rays), i.e. a ray is the point (u, v) on the plane D_k = 1 through
-//                   P, and it can only hit a triangle whose central projection onto that plane
-//                   contains (u, v).  First test of a pair: (u, v) inside the projection's
-//                   bounding square (k_pack_apex writes one per triangle and axis, allowances
-//                   included): two subtractions and a maximum, 3.6 VALU instructions per pair
-//                   with the reduction over a lane's rays.  The rare path behind it is the
-//                   full inside test on the four dot products.
+//   k_sweep_apex    any-hit, ray by ray, for the shadow rays of up to four lights (the phases too
+//                   small for the cell-lattice sweep of rt_sweep_cells.hip, and tile culling).
+//                   Directions are scaled to a unit dominant component, D' = D / D_k (rays binned
+//                   by that axis, k_bin_rays), i.e. a ray is the point (u, v) on the plane
+//                   D_k = 1 through P, and it can only hit a triangle whose central projection
+//                   onto that plane contains (u, v).  First test of a pair: the u half of the
+//                   projection's bounding square (k_pack_apex writes one per triangle and axis,
+//                   allowances included), |u - cu| <= rho: a subtraction per pair and a three-way
+//                   minimum per two, 13 VALU instructions per 8 pairs; the wave completes the
+//                   square for the few triangles that have one of its rays in their u strip, and
+//                   the rare path behind that is the full inside test on the four dot products.
 //                   Triangles in the order of their solid angle at the light, triangle ranges
 //                   with survivor compaction in between, triangle chunks that share a ray's
 //                   state through atomics, an occluder cache in front (host side:
 //                   trace_shadow_rays in rt_api.hip).
 //   k_sweep_raster  closest hit for the pixel grid.  D = (X, Y, ez) with integer X, Y and a
 //                   constant ez that k_pack_apex folds into the z components.  Each lane owns
-//                   up to RT_RASTER_RPL pixels, a lattice of rows and columns of the image.
+//                   up to 4096 pixels, a lattice of rows and columns of the image.
 //                   First test of a pair: the pixel against the bounding box of the
 //                   triangle's projection onto the image plane (k_pack_apex writes one per
 //                   triangle, allowances included).  A pixel is in the box when its column is
 //                   in the box's x extent and its row in the y extent, so a lane evaluates one
-//                   interval test per column and per row of its lattice -- 146 VALU instructions
-//                   per 2048 pairs (64 columns, 32 rows) -- and every pixel's verdict is the one it would get on its
-//                   own.  Primary rays leave P, which fixes the sign of det for a hit, so
-//                   k_pack_apex orients every triangle (sign layout) for the rare path's
+//                   interval test per column and per row of its lattice -- 194 VALU instructions
+//                   per 4096 pairs (64 columns, 64 rows) -- and every pixel's verdict is the one it
+//                   would get on its own.  Primary rays leave P, which fixes the sign of det for a
+//                   hit, so k_pack_apex orients every triangle (sign layout) for the rare path's
 //                   inside test.
 //
 // The sweeps stream what their first test reads through LDS in tiles of RT_TILE triangles,
@@ -525,9 +527,9 @@ k_sweep_raster(const SweepArgs A)
 // ------------------------------------------------------------------------------------------
 // any-hit sweep for rays that end at the apex (shadow rays of one light)
 // ------------------------------------------------------------------------------------------
-// The sign test U * W' >= -c does not change when the direction is scaled by any non-zero
+// The bounding-square and inside tests do not change when the direction is scaled by any non-zero
 // number, so every ray uses D' = D / D_k with k its dominant axis: D'_k = 1 exactly and the
-// other two components are at most 1 in magnitude.  Rays are binned by k beforehand
+// other two components, (u, v), are at most 1 in magnitude.  Rays are binned by k beforehand
 // (k_bin_rays), a workgroup handles rays of one k, and a dot product D'.p costs two FMAs
 // instead of a multiply and two:  U = fma(u, p_i, fma(v, p_j, p_k)).
 struct ApexRay {

@@ -92,96 +92,130 @@ __device__ __forceinline__ bool finish_cell(const CellArgs& A, const CellCtx& X,
     return false;
 }
 
-// Some cell of the wave lies inside the triangle's grown box.  The cells of the wave's footprint
-// whose centre is in the box form a rectangle of the grid, and because the rays are sorted by
+// Running sum over the wave's 64 lanes (inclusive).
+__device__ __forceinline__ int wave_scan(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(v, off);
+        v += lane >= off ? t : 0;
+    }
+    return v;
+}
+
+// The first lane whose running sum `incl` exceeds r (63 when none does).
+__device__ __forceinline__ int wave_search(int incl, int r)
+{
+    int l = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+        const int v = __shfl(incl, l + step - 1);
+        l += v <= r ? step : 0;
+    }
+    return l > 63 ? 63 : l;
+}
+
+// The rare path, for the triangles of a quarter tile (32 of them) that had some cell of the wave
+// inside their grown box -- `passed`, one bit each.  The cells of the wave's footprint whose
+// centre is in a triangle's box form a rectangle of the grid, and because the rays are sorted by
 // cell, row by row, the rays of one row of the rectangle are one run of the ray array: from the
 // first ray at or behind the row's first cell to the first ray behind its last (the cell table
 // holds, for every cell, the number of rays in the cells before it).  The whole wave works
-// through the rectangle together: a lane per row looks up the row's run, and the rays found are
-// dealt to the lanes one each (a running sum over the rows' ray counts and a search in it,
-// through lane permutes) -- a lane's own cells hold anything from no ray to hundreds, and walked
-// lane by lane the wave would wait for its busiest lane's chain of dependent loads.  Every ray
-// of every such cell is tested against the triangle on its own.
-// box: the triangle's (cx, rx, cy, ry), wave-uniform; fx0, fy0: the first cell of the footprint.
+// through all of the quarter's rectangles together:
+//   * lane k < 32 takes triangle k's box and works out its rectangle;
+//   * the (triangle, row) pairs of all rectangles are dealt to the lanes, 64 at a time (a running
+//     sum over the rectangles' row counts and a search in it, through lane permutes), and every
+//     lane looks up its row's run of rays;
+//   * the rays of those runs are dealt to the lanes the same way, and every lane tests its ray
+//     against its triangle: first against the triangle's square (the box less the half cell it
+//     was grown by), then the inside test with the triangle's planes fetched from memory.
+// Every ray of every passing cell is tested against the cell's triangle on its own; what the
+// batching buys is that the dependent memory accesses of a path taken for every few triangles
+// (row look-up, ray, planes, the ray's state) are waited for once per quarter tile instead of
+// once per triangle, with all 64 lanes at work.
+// qbox: the quarter's 32 boxes in LDS; tri0: plane entry of its first triangle.
 template <int R>
-__device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, const float4& vbox, int tri, int fx0,
-                                           int fy0, int lane, unsigned& tested, unsigned& visited)
+__device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, const float4* qbox, int tri0,
+                                           unsigned passed, int fx0, int fy0, float su, float sv, int lane,
+                                           unsigned& tested, unsigned& visited)
 {
     using L = CellLane<R>;
-    // (scalar copies: every bound below is wave-uniform and the loops run on scalar counters)
-    const float bx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.x)));
-    const float rx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.y)));
-    const float by = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.z)));
-    const float ry = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.w)));
-    // The cells to visit: integer centres x with |x - cx| <= rho hu + 1/2 for the exact centre and
-    // extent.  The stored extent exceeds that by 2^-9 cell, more than the roundings of the stored
-    // centre and of the two bounds here, so the integers between the computed bounds include them.
-    const float xl = __builtin_fmaxf(bx - rx, (float)fx0), xh = __builtin_fminf(bx + rx, (float)(fx0 + L::WW - 1));
-    const float yl = __builtin_fmaxf(by - ry, (float)fy0), yh = __builtin_fminf(by + ry, (float)(fy0 + L::WH - 1));
-    if (!(xl <= xh) || !(yl <= yh)) return;
-    const int x_lo = (int)__builtin_ceilf(xl), y_lo = (int)__builtin_ceilf(yl);
-    const int nx = (int)__builtin_floorf(xh) - x_lo + 1, ny = (int)__builtin_floorf(yh) - y_lo + 1;
-    if (nx <= 0 || ny <= 0) return;
-    // the triangle's square in (u, v) and its planes (tri is wave-uniform)
-    const float4* __restrict__ g = X.planes + tri;
-    const float4 sq = g[X.square_plane];
-    const float4 P = g[0], Hh = g[2 * X.plane_stride], N = g[3 * X.plane_stride];
-    const float margin = g[X.plane_stride].w;
-    // dot_ax of rt_sweep_apex.hip: D' = (1, u, v), (u, 1, v) or (u, v, 1)
-    const int ax = X.axis;
-    const float Pp[3] = {ax == 0 ? P.y : P.x, ax == 2 ? P.y : P.z, ax == 0 ? P.x : (ax == 1 ? P.y : P.z)};
-    const float Hp[3] = {ax == 0 ? Hh.y : Hh.x, ax == 2 ? Hh.y : Hh.z, ax == 0 ? Hh.x : (ax == 1 ? Hh.y : Hh.z)};
-    const float Np[3] = {ax == 0 ? N.y : N.x, ax == 2 ? N.y : N.z, ax == 0 ? N.x : (ax == 1 ? N.y : N.z)};
-    const float qnan = __builtin_nanf("");
+    // lane k: the rectangle of triangle k (no rows when the triangle did not pass, or the box
+    // misses the footprint after all)
+    int x_lo = 0, nx = 0, y_lo = 0, ny = 0;
+    if (lane < 32 && ((passed >> lane) & 1u)) {
+        const float4 box = qbox[lane];
+        // The cells to visit: integer centres x with |x - cx| <= rho hu + 1/2 for the exact centre
+        // and extent.  The stored extent exceeds that by 2^-9 cell, more than the roundings of the
+        // stored centre and of the two bounds here, so the integers between the computed bounds
+        // include them.
+        const float xl = __builtin_fmaxf(box.x - box.y, (float)fx0), xh = __builtin_fminf(box.x + box.y, (float)(fx0 + L::WW - 1));
+        const float yl = __builtin_fmaxf(box.z - box.w, (float)fy0), yh = __builtin_fminf(box.z + box.w, (float)(fy0 + L::WH - 1));
+        if (xl <= xh && yl <= yh) {
+            x_lo = (int)__builtin_ceilf(xl);
+            y_lo = (int)__builtin_ceilf(yl);
+            nx = (int)__builtin_floorf(xh) - x_lo + 1;
+            ny = (int)__builtin_floorf(yh) - y_lo + 1;
+            if (nx <= 0 || ny <= 0) nx = ny = 0;
+        }
+    }
+    const int rows_incl = wave_scan(ny, lane);
+    const int rows_total = __builtin_amdgcn_readlane(rows_incl, 63);
+    const int rows_excl = rows_incl - ny;
     const int* __restrict__ table = A.table + X.cell_base;
-    for (int base = 0; base < ny; base += 64) {
-        const int j = base + lane;
+    const int ax = X.axis;
+    const float qnan = __builtin_nanf("");
+    for (int p0 = 0; p0 < rows_total; p0 += 64) {
+        // this lane's (triangle, row) pair
+        const int p = p0 + lane;
+        const int e = wave_search(rows_incl, p);
+        const int j = p - __shfl(rows_excl, e);
+        const int ex = __shfl(x_lo, e), enx = __shfl(nx, e), ey = __shfl(y_lo, e);
         int first = 0, n = 0;
-        if (j < ny) {
-            const int at = ((y_lo + j) << X.gu_log2) + x_lo;
+        if (p < rows_total) {
+            const int at = ((ey + j) << X.gu_log2) + ex;
             first = table[at];
-            n = table[at + nx] - first;      // (behind a row's last cell comes the next row's first; the table has one more entry than cells)
+            n = table[at + enx] - first;        // (behind a row's last cell comes the next row's first; the table has one more entry than cells)
             ++visited;
         }
-        // running sum of the ray counts over the 64 rows
-        int incl = n;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            incl += lane >= off ? t : 0;
-        }
-        const int total = A.debug_skip == 2 ? 0 : __builtin_amdgcn_readlane(incl, 63);
-        const int excl = incl - n;
-
-        for (int r0 = 0; r0 < total; r0 += 64) {
+        const int rays_incl = wave_scan(n, lane);
+        const int rays_total = A.debug_skip == 2 ? 0 : __builtin_amdgcn_readlane(rays_incl, 63);
+        const int rays_excl = rays_incl - n;
+        for (int r0 = 0; r0 < rays_total; r0 += 64) {
             const int r = r0 + lane;
-            // the row of ray r: the first one whose running sum exceeds r
-            int l = 0;
-#pragma unroll
-            for (int step = 32; step > 0; step >>= 1) {
-                const int v = __shfl(incl, l + step - 1);
-                l += v <= r ? step : 0;
-            }
-            l = l > 63 ? 63 : l;
-            const int i = __shfl(first, l) + (r - __shfl(excl, l));
-            if (r < total) {
+            const int q = wave_search(rays_incl, r);        // the pair whose run holds ray r
+            const int i = __shfl(first, q) + (r - __shfl(rays_excl, q));
+            const int k = __shfl(e, q);                     // ... and its triangle
+            if (r < rays_total) {
                 const float2 rec = A.rays[i];
+                const float4 box = qbox[k];
                 ++tested;
-                // (a retired ray's u is NaN and never passes)
-                if (max_abs(rec.x - sq.x, rec.y - sq.y) <= sq.z && A.debug_skip != 3 &&
-                    finish_cell(A, X, rec, i, tri, Pp, margin, Hp, Hh.w, Np, N.w))
-                    A.rays[i].x = qnan;
+                // The ray against the triangle's square, in cell units: the box less the half cell it
+                // was grown by (what is left of the growth, 2^-9 cell, covers the roundings here).
+                // A retired ray's u is NaN and never passes.
+                const float xr = __builtin_fmaf(rec.x, su, su - 0.5f), yr = __builtin_fmaf(rec.y, sv, sv - 0.5f);
+                if (__builtin_fabsf(xr - box.x) <= box.y - 0.5f && __builtin_fabsf(yr - box.z) <= box.w - 0.5f &&
+                    A.debug_skip != 3) {
+                    const int tri = tri0 + k;
+                    const float4* __restrict__ g = X.planes + tri;
+                    const float4 P = g[0], Hh = g[2 * X.plane_stride], N = g[3 * X.plane_stride];
+                    const float margin = g[X.plane_stride].w;
+                    // dot_ax of rt_sweep_apex.hip: D' = (1, u, v), (u, 1, v) or (u, v, 1)
+                    const float Pp[3] = {ax == 0 ? P.y : P.x, ax == 2 ? P.y : P.z, ax == 0 ? P.x : (ax == 1 ? P.y : P.z)};
+                    const float Hp[3] = {ax == 0 ? Hh.y : Hh.x, ax == 2 ? Hh.y : Hh.z, ax == 0 ? Hh.x : (ax == 1 ? Hh.y : Hh.z)};
+                    const float Np[3] = {ax == 0 ? N.y : N.x, ax == 2 ? N.y : N.z, ax == 0 ? N.x : (ax == 1 ? N.y : N.z)};
+                    if (finish_cell(A, X, rec, i, tri, Pp, margin, Hp, Hh.w, Np, N.w)) A.rays[i].x = qnan;
+                }
             }
         }
     }
 }
 
 // One triangle against the lane's R cells: RX columns SX cells apart, RY rows SY apart.
-// box = (cx, rx, cy, ry) in cell units.
+// box = (cx, rx, cy, ry) in cell units.  Returns whether some lane of the wave has a column and
+// a row of its lattice inside the box (wave-uniform).
 template <int R>
-__device__ __forceinline__ void cells_triangle(const CellArgs& A, const CellCtx& X, const float4& box, int tri,
-                                               float X0, float Y0, int fx0, int fy0, int lane, unsigned& tested,
-                                               unsigned& visited, unsigned& entered)
+__device__ __forceinline__ bool cells_triangle(const float4& box, float X0, float Y0)
 {
     using L = CellLane<R>;
     constexpr float KX = (float)L::SX, KY = (float)L::SY;
@@ -195,12 +229,7 @@ __device__ __forceinline__ void cells_triangle(const CellArgs& A, const CellCtx&
 #pragma unroll
     for (int j = 0; j + 1 < L::RY; j += 2)
         accy = min3_abs(accy, j == 0 ? e0 : e0 + KY * (float)j, e0 + KY * (float)(j + 1));
-    // some lane has a column and a row of its lattice inside the box: the wave goes through the
-    // box's cells together
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(accx <= box.y && accy <= box.w) != 0, 0)) {
-        ++entered;
-        if (A.debug_skip != 1) cells_rare<R>(A, X, box, tri, fx0, fy0, lane, tested, visited);
-    }
+    return __builtin_amdgcn_ballot_w64(accx <= box.y && accy <= box.w) != 0;
 }
 
 // Stages the boxes of `count` (<= kGroup) tiles: tile t and the ones `stride` tiles further on.
@@ -254,6 +283,7 @@ k_sweep_cells(const CellArgs A)
     const int fx = f & ((1 << cs.fp_cols_log2) - 1), fy = f >> cs.fp_cols_log2;
     const int fx0 = fx * L::WW, fy0 = fy * L::WH;               // the footprint's first cell
     const float X0 = (float)(fx0 + lane % L::SX), Y0 = (float)(fy0 + lane / L::SX);   // the lane's first cell
+    const float su = (float)(1 << (cs.gu_log2 - 1)), sv = (float)(1 << (cs.gv_log2 - 1));   // cells per unit of u, v
     const float4* __restrict__ boxes = A.boxes + (long)s * A.num_tris_padded;
 
     // This workgroup's share of the triangle range: the tiles blockIdx.y, blockIdx.y + gridDim.y, ...
@@ -283,17 +313,23 @@ k_sweep_cells(const CellArgs A)
             // (the address in a vector register the compiler cannot see through, advanced once per
             // kUnroll triangles, the reads at immediate offsets, one triangle ahead; the last read
             // of a quarter touches the entry behind it and is not used)
-            unsigned box_at = lds_address(base + sub * RT_TILE + wave * (RT_TILE / 4));
+            const float4* qbox = base + sub * RT_TILE + wave * (RT_TILE / 4);
+            unsigned box_at = lds_address(qbox);
             asm volatile("" : "+v"(box_at));
             float4 next = lds_read_float4(box_at);
+            unsigned passed = 0;            // the quarter's triangles with a cell of the wave in their box
             for (int j4 = 0; j4 < RT_TILE / 4; j4 += kUnroll) {
 #pragma unroll
                 for (int k = 0; k < kUnroll; ++k) {
                     const float4 box = next;
                     next = lds_read_float4(box_at + 16u * (unsigned)(k + 1));
-                    cells_triangle<R>(A, X, box, tri0 + j4 + k, X0, Y0, fx0, fy0, lane, tested, visited, entered);
+                    if (cells_triangle<R>(box, X0, Y0)) passed |= 1u << (j4 + k);
                 }
                 box_at += 16u * kUnroll;
+            }
+            if (__builtin_expect(passed != 0, 0)) {
+                entered += __builtin_popcount(passed);
+                if (A.debug_skip != 1) cells_rare<R>(A, X, qbox, tri0, passed, fx0, fy0, su, sv, lane, tested, visited);
             }
         }
         __builtin_amdgcn_s_waitcnt(0);
@@ -307,7 +343,7 @@ k_sweep_cells(const CellArgs A)
         }
         if (lane == 0 && tested) atomicAdd(A.ray_pairs, (unsigned long long)tested);
         if (lane == 0 && visited) atomicAdd(A.ray_pairs + 2, (unsigned long long)visited);
-        if (lane == 0 && entered) atomicAdd(A.ray_pairs + 3, (unsigned long long)entered);
+        if (lane == 0 && entered) atomicAdd(A.ray_pairs + 3, (unsigned long long)entered);   // (wave-uniform)
     }
 }
 

@@ -29,12 +29,15 @@ def test_two_ranks_on_one_gpu_assemble_the_single_rank_frame():
                 "--verify", "--no-cpu-baseline"])
     assert d["n_gpus"] == 2 and d["verify"]["screen_equals_single_rank_render"] is True
     assert d["rays_per_frame"]["primary"] == 640 * 480
+    # what torch.distributed itself says about the run: two ranks went through the gather
+    assert d["comm"]["world_size"] == 2 and d["comm"]["backend"] == "gloo" and d["comm"]["gather_ms"] > 0
 
 
 def test_rccl_gather_with_one_rank():
     d = _bench([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--workload",
                 "teapot_class_480p", "--force-dist", "--verify", "--no-cpu-baseline"])
     assert d["verify"]["screen_equals_single_rank_render"] is True
+    assert d["comm"]["world_size"] == 1 and d["comm"]["backend"] == "nccl" and d["comm"]["gather_ms"] > 0
 
 
 def test_frame_sequence_is_split_by_frames():
@@ -49,6 +52,8 @@ def test_frame_sequence_is_split_by_frames():
     assert d["verify"]["screen_equals_single_rank_render"] is True
     assert d["rays_per_frame"]["primary"] == 2 * 3840 * 2160          # two frames per step
     assert abs(d["frames_per_s"] * d["ms_per_step"] * 1e-3 - 2.0) < 1e-6
+    assert d["frames"]["per_rank"] == [2, 2] and d["frames"]["whole_frames_per_rank"] is True
+    assert len(d["frames"]["seconds_per_rank"]) == 2 and d["comm"]["world_size"] == 2
 
 
 def test_single_process_mode_drives_the_devices_itself():
