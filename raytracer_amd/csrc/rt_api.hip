@@ -692,11 +692,13 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     a.chunks = chunks;
     a.waves_x = waves_x;
     a.regular = regular ? 1 : 0;
+    a.debug_skip = getenv("RT_AMD_RASTER_SKIP_RARE") ? atoi(getenv("RT_AMD_RASTER_SKIP_RARE")) : 0;
     a.cull = rt_tile_culling() ? 1 : 0;
     a.tests = nullptr;
 #ifdef RT_RASTER_CHECK_INTERVAL
     a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
 #endif
+
     a.tri_begin = 0; a.tri_end = sc->num_tris_padded;
     // pairs of the band's own pixels (the lanes of a wave that reaches beyond the image's edge
     // execute their tests too; those are not counted)

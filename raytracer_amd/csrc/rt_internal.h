@@ -306,6 +306,7 @@ struct SweepArgs {
     float* best_hi;
     unsigned long long* tests;   // pairs evaluated, accumulated per workgroup (may be nullptr)
     int cull;               // apex sweeps: test every tile's triangles against the wave's whole bundle first
+    int debug_skip;         // measurement only: the pixel-grid sweep leaves its rare path out (wrong results)
 };
 int rt_launch_sweep_rays(const SweepArgs& a, bool anyhit, hipStream_t st);
 // rt_sweep_apex.hip: a.planes = apex planes (RT_APEX_PLANES of them)

@@ -244,10 +244,79 @@ struct RasterGroups {
     static_assert(G >= 1 && RG * G == L::RY, "a lane's rows split evenly over the wave's 16-row groups");
 };
 
+// Some pixel of the wave lies in the triangle's box: the pixels of the wave's block that do form
+// a rectangle of the image (per 16-row group of the block, whose rows are consecutive image
+// rows), and the whole wave works through it together, 64 pixels at a time -- a lane's own
+// pixels in a box are a handful of one column of its lattice, and walked lane by lane the wave
+// runs as many rounds as the box is tall with a quarter of its lanes at work.  Every pixel of
+// the rectangle gets the inside test of finish_raster on its own.
+// vbox: the triangle's (cx, rx, cy, ry), wave-uniform; wave_x0, wave_y0: the block's first pixel
+// and local row; rows_y: the Y of the block's local rows (LDS, NaN beyond the band).
+// The rectangle's bounds are rounded inwards to whole pixels: the box was grown by 0.01 pixel and
+// more for the roundings of a test on it, a hundred times what the bounds' own roundings come to.
+template <int R>
+__device__ __forceinline__ void raster_rare_block(const SweepArgs& A, const float4& vbox, int tri, int wave_x0,
+                                                  int wave_y0, const float* rows_y, int lane)
+{
+    using L = RasterLane<R>;
+    constexpr int G = RasterGroups<R>::G;
+    constexpr float COLS = (float)RT_RASTER_COLS;
+    const float bx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.x)));
+    const float rx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.y)));
+    const float by = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.z)));
+    const float ry = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.w)));
+    // columns: pixels px with |(px - W/2) / COLS - cx| <= rx inside the block and the image
+    const int x_end = wave_x0 + L::WW < A.W ? wave_x0 + L::WW : A.W;
+    const float half_w = (float)(A.W / 2);
+    const float xl = __builtin_fmaxf(__builtin_fmaf(COLS, bx - rx, half_w), (float)wave_x0);
+    const float xh = __builtin_fminf(__builtin_fmaf(COLS, bx + rx, half_w), (float)(x_end - 1));
+    if (!(xl <= xh)) return;
+    const int x_lo = (int)__builtin_ceilf(xl), nx = (int)__builtin_floorf(xh) - x_lo + 1;
+    if (nx <= 0) return;
+    // rows: per group of 16 consecutive rows, those with |Y - cy| <= ry that exist
+    int first[G], count[G], ny = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float Yg = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(rows_y[RT_TILE_H * g])));
+        int left = A.rows.rows - (wave_y0 + RT_TILE_H * g);         // rows of the group that exist
+        left = left > RT_TILE_H ? RT_TILE_H : left;
+        first[g] = 0;
+        count[g] = 0;
+        const float lo = __builtin_fmaxf(by - ry - Yg, 0.0f), hi = __builtin_fminf(by + ry - Yg, (float)(left - 1));
+        if (Yg == Yg && lo <= hi) {
+            first[g] = (int)__builtin_ceilf(lo);
+            const int n = (int)__builtin_floorf(hi) - first[g] + 1;
+            count[g] = n > 0 ? n : 0;
+        }
+        ny += count[g];
+    }
+    if (ny == 0) return;
+    const float4* __restrict__ g4 = A.planes + tri;
+    const float4 P = g4[0], Hh = g4[2 * A.plane_stride], N = g4[3 * A.plane_stride];
+    const float margin = g4[A.plane_stride].w;
+    const int npix = nx * ny;
+    const float inv_nx = 1.0f / (float)nx;
+    for (int k = lane; k < npix; k += 64) {
+        // (k + 1/2) / nx: the quotient's rounding stays far below 1 / (2 nx) for k < 2^18, nx <= 2^12
+        int r = (int)__builtin_floorf(((float)k + 0.5f) * inv_nx);
+        const int c = k - r * nx;
+        int row = 0;                    // local row within the block
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const bool here = r >= 0 && r < count[g];
+            row = here ? RT_TILE_H * g + first[g] + r : row;
+            r = here ? -1 : r - count[g];
+        }
+        const int px = x_lo + c;
+        finish_raster(A, (long)(wave_y0 + row) * A.W + px, tri, P, margin, Hh, N, (float)(px - A.W / 2) * (1.0f / COLS),
+                      rows_y[row]);
+    }
+}
+
 template <int R>
 __device__ __forceinline__ void raster_triangle_reg(const SweepArgs& A, const float4& box, int tri, float Xs0,
-                                                    const float (&YG)[RasterGroups<R>::G], const float* y_of_row,
-                                                    int px0, int lr0, long slot0)
+                                                    const float (&YG)[RasterGroups<R>::G], const float* rows_y,
+                                                    int wave_x0, int wave_y0, int lane)
 {
     using L = RasterLane<R>;
     constexpr int RX = L::RX, G = RasterGroups<R>::G, RG = RasterGroups<R>::RG;
@@ -268,54 +337,42 @@ __device__ __forceinline__ void raster_triangle_reg(const SweepArgs& A, const fl
         for (int j = 0; j + 1 < RG; j += 2)
             accy = min3_abs(accy, j == 0 ? e[g] : e[g] + KY * (float)j, e[g] + KY * (float)(j + 1));
     }
-    if (__builtin_expect(accx <= box.y && accy <= box.w, 0)) {
-        // the columns of the box: c with |d0 + KX c| <= rx, one more on either side for the rounding
-        // of these two bounds (the inside test decides about every pixel it is given)
-        int c_lo = (int)__builtin_floorf(__builtin_fmaxf((-box.y - d0) * (1.0f / KX), 0.0f)) - 1;
-        int c_hi = (int)__builtin_ceilf(__builtin_fminf((box.y - d0) * (1.0f / KX), (float)(RX - 1))) + 1;
-        c_lo = c_lo < 0 ? 0 : c_lo;
-        c_hi = c_hi > RX - 1 ? RX - 1 : c_hi;
+    const bool mine = accx <= box.y && accy <= box.w;       // some pixel of this lane's lattice is in the box
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine) != 0 && A.debug_skip != 1, 0)) {
 #if RT_RASTER_CHECK_INTERVAL
+        // every pixel of the lane's lattice that passes the test above must lie in the rectangle
+        // the wave is about to work through (computed here the same way)
         {
-            unsigned long long pass = 0;
+            constexpr float COLS = (float)RT_RASTER_COLS;
+            const int x_end = wave_x0 + L::WW < A.W ? wave_x0 + L::WW : A.W;
+            const float half_w = (float)(A.W / 2);
+            const float xl = __builtin_fmaxf(__builtin_fmaf(COLS, box.x - box.y, half_w), (float)wave_x0);
+            const float xh = __builtin_fminf(__builtin_fmaf(COLS, box.x + box.y, half_w), (float)(x_end - 1));
+            const int x_lo = (int)__builtin_ceilf(xl), x_hi = (int)__builtin_floorf(xh);
+            const int px0 = wave_x0 + lane % L::SX, lr0 = wave_y0 + lane / L::SX;
+            unsigned long long missed = 0;
 #pragma unroll
-            for (int k = 0; k < RX; ++k) pass |= (__builtin_fabsf(d0 + KX * (float)k) <= box.y ? 1ull : 0ull) << k;
-            const unsigned long long inside =
-                c_lo > c_hi ? 0ull : (((c_hi >= 63 ? 0ull : (2ull << c_hi)) - 1ull) & ~((1ull << c_lo) - 1ull));
-            if ((pass & ~inside) && A.tests) atomicAdd(A.tests, 1ull << 48);
+            for (int c = 0; c < RX; ++c) {
+                const int px = px0 + L::SX * c;
+                if (__builtin_fabsf(d0 + KX * (float)c) <= box.y && px < A.W && !(xl <= xh && px >= x_lo && px <= x_hi)) ++missed;
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int j = 0; j < RG; ++j) {
+                    const int lrow = lane / L::SX + RT_TILE_H * g + L::SY * j;       // local row within the block
+                    if (!(__builtin_fabsf(e[g] + KY * (float)j) <= box.w) || lr0 + RT_TILE_H * g + L::SY * j >= A.rows.rows) continue;
+                    const float Yg = rows_y[RT_TILE_H * g];
+                    int left = A.rows.rows - (wave_y0 + RT_TILE_H * g);
+                    left = left > RT_TILE_H ? RT_TILE_H : left;
+                    const float lo = __builtin_fmaxf(box.z - box.w - Yg, 0.0f), hi = __builtin_fminf(box.z + box.w - Yg, (float)(left - 1));
+                    const int in_g = lrow - RT_TILE_H * g;
+                    if (!(lo <= hi && in_g >= (int)__builtin_ceilf(lo) && in_g <= (int)__builtin_floorf(hi))) ++missed;
+                }
+            if (missed && A.tests) atomicAdd(A.tests, missed << 48);
         }
 #endif
-        const float4* __restrict__ g4 = A.planes + tri;
-        const float4 P = g4[0], Hh = g4[2 * A.plane_stride], N = g4[3 * A.plane_stride];
-        const float margin = g4[A.plane_stride].w;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            // the rows of the box in this group, found like the columns (a group beyond the band
-            // carries NaN: its bounds come out as the whole group, and no row of it passes)
-            int j_lo = (int)__builtin_floorf(__builtin_fmaxf((-box.w - e[g]) * (1.0f / KY), 0.0f)) - 1;
-            int j_hi = (int)__builtin_ceilf(__builtin_fminf((box.w - e[g]) * (1.0f / KY), (float)(RG - 1))) + 1;
-            j_lo = j_lo < 0 ? 0 : j_lo;
-            j_hi = j_hi > RG - 1 ? RG - 1 : j_hi;
-#if RT_RASTER_CHECK_INTERVAL
-            {
-                unsigned pass = 0;
-#pragma unroll
-                for (int k = 0; k < RG; ++k) pass |= (__builtin_fabsf(e[g] + KY * (float)k) <= box.w ? 1u : 0u) << k;
-                const unsigned inside = j_lo > j_hi ? 0u : (((j_hi >= 31 ? 0u : (2u << j_hi)) - 1u) & ~((1u << j_lo) - 1u));
-                if ((pass & ~inside) && A.tests) atomicAdd(A.tests, 1ull << 48);
-            }
-#endif
-            for (int jj = j_lo; jj <= j_hi; ++jj) {
-                if (!(__builtin_fabsf(e[g] + KY * (float)jj) <= box.w)) continue;
-                const int j = g * RG + jj;
-                const float Yj = y_of_row[L::SY * j];
-                for (int c = c_lo; c <= c_hi; ++c)
-                    if (__builtin_fabsf(d0 + KX * (float)c) <= box.y &&
-                        px0 + L::SX * c < A.W && lr0 + L::SY * j < A.rows.rows)      // ... and the pixel exists
-                        finish_raster(A, slot0 + (long)(j * L::SY) * A.W + L::SX * c, tri, P, margin, Hh, N,
-                                      Xs0 + KX * (float)c, Yj);
-            }
-        }
+        raster_rare_block<R>(A, box, tri, wave_x0, wave_y0, rows_y, lane);
     }
 }
 
@@ -505,7 +562,7 @@ k_sweep_raster(const SweepArgs A)
                         const float4 box = next;
                         next = lds_read_float4(box_at + 16u * (unsigned)(k + 1));
                         if constexpr (REG)
-                            raster_triangle_reg<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, YG, y_of_row, px0, lr0, slot0);
+                            raster_triangle_reg<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, YG, row_y[wave], wave_x0, wave_y0, lane);
                         else
                             raster_triangle<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, Y, y_of_row, px0, lr0, slot0);
                     }
