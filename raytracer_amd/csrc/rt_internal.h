@@ -78,12 +78,12 @@ constexpr int RT_LIGHT_PLANES = RT_APEX_PLANES + 3;
 constexpr int RT_APEX_LIGHTS = 4;   // lights swept per any-hit launch (plane sets kept side by side)
 constexpr int RT_APEX_SETS = 3 * RT_APEX_LIGHTS;    // ray sets per launch: light x dominant axis
 // A lane's rpl pixels in the pixel-grid sweep are a block of this many rows (by rpl / rows columns).
-constexpr int rt_raster_lane_rows(int rpl) { return rpl >= 4096 ? 64 : (rpl >= 2048 ? 32 : (rpl >= 256 ? 16 : (rpl >= 64 ? 8 : (rpl >= 16 ? 4 : (rpl >= 4 ? 2 : 1))))); }
+constexpr int rt_raster_lane_rows(int rpl) { return rpl >= 16384 ? 256 : rpl >= 8192 ? 128 : rpl >= 4096 ? 64 : (rpl >= 2048 ? 32 : (rpl >= 256 ? 16 : (rpl >= 64 ? 8 : (rpl >= 16 ? 4 : (rpl >= 4 ? 2 : 1))))); }
 // A wave's 64 lanes cover this many local rows (two 16-row blocks with 2048 pixels per lane, four with 4096) ...
-constexpr int rt_raster_wave_rows(int rpl) { return rpl >= 4096 ? 4 * RT_TILE_H : (rpl >= 2048 ? 2 * RT_TILE_H : RT_TILE_H); }
+constexpr int rt_raster_wave_rows(int rpl) { return rpl >= 16384 ? 16 * RT_TILE_H : rpl >= 8192 ? 8 * RT_TILE_H : rpl >= 4096 ? 4 * RT_TILE_H : (rpl >= 2048 ? 2 * RT_TILE_H : RT_TILE_H); }
 // 4096 pixels per lane (64 rows) exist only in the regular-row form of the sweep, which steps from
 // row to row by a constant instead of holding every row's coordinate in a register
-constexpr int RT_RASTER_RPL_REGULAR = 4096;
+constexpr int RT_RASTER_RPL_REGULAR = 16384;
 // ... by this many pixel columns
 constexpr int rt_raster_wave_cols(int rpl) { return 64 * rpl / rt_raster_wave_rows(rpl); }
 // Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels = rows x columns): the

@@ -244,22 +244,22 @@ struct RasterGroups {
     static_assert(G >= 1 && RG * G == L::RY, "a lane's rows split evenly over the wave's 16-row groups");
 };
 
-// Some pixel of the wave lies in the triangle's box: the pixels of the wave's block that do form
-// a rectangle of the image (per 16-row group of the block, whose rows are consecutive image
-// rows), and the whole wave works through it together, 64 pixels at a time -- a lane's own
-// pixels in a box are a handful of one column of its lattice, and walked lane by lane the wave
-// runs as many rounds as the box is tall with a quarter of its lanes at work.  Every pixel of
-// the rectangle gets the inside test of finish_raster on its own.
+// Some pixel of the wave lies in the triangle's box.  The pixels of the wave's block that do are
+// the crossing of a run of its columns with those of its rows whose Y lies in the box's y extent,
+// and the whole wave works through them together, 64 pixels at a time -- a lane's own pixels
+// in a box are a handful of one column of its lattice, and walked lane by lane the wave runs as
+// many rounds as the box is tall with a quarter of its lanes at work.  Every one of those pixels
+// gets the inside test of finish_raster on its own.
 // vbox: the triangle's (cx, rx, cy, ry), wave-uniform; wave_x0, wave_y0: the block's first pixel
-// and local row; rows_y: the Y of the block's local rows (LDS, NaN beyond the band).
-// The rectangle's bounds are rounded inwards to whole pixels: the box was grown by 0.01 pixel and
-// more for the roundings of a test on it, a hundred times what the bounds' own roundings come to.
+// and local row; rows_y: the Y of the block's local rows (LDS, NaN beyond the band); row_list:
+// LDS scratch of the wave, one entry per local row of the block.
+// The column bounds are rounded inwards to whole pixels: the box was grown by 0.01 pixel and more
+// for the roundings of a test on it, a hundred times what the bounds' own roundings come to.
 template <int R>
 __device__ __forceinline__ void raster_rare_block(const SweepArgs& A, const float4& vbox, int tri, int wave_x0,
-                                                  int wave_y0, const float* rows_y, int lane)
+                                                  int wave_y0, const float* rows_y, int* row_list, int lane)
 {
     using L = RasterLane<R>;
-    constexpr int G = RasterGroups<R>::G;
     constexpr float COLS = (float)RT_RASTER_COLS;
     const float bx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.x)));
     const float rx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vbox.y)));
@@ -273,22 +273,15 @@ __device__ __forceinline__ void raster_rare_block(const SweepArgs& A, const floa
     if (!(xl <= xh)) return;
     const int x_lo = (int)__builtin_ceilf(xl), nx = (int)__builtin_floorf(xh) - x_lo + 1;
     if (nx <= 0) return;
-    // rows: per group of 16 consecutive rows, those with |Y - cy| <= ry that exist
-    int first[G], count[G], ny = 0;
+    // rows: the local rows with |Y - cy| <= ry, listed in LDS (a row beyond the band has Y = NaN)
+    int ny = 0;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const float Yg = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(rows_y[RT_TILE_H * g])));
-        int left = A.rows.rows - (wave_y0 + RT_TILE_H * g);         // rows of the group that exist
-        left = left > RT_TILE_H ? RT_TILE_H : left;
-        first[g] = 0;
-        count[g] = 0;
-        const float lo = __builtin_fmaxf(by - ry - Yg, 0.0f), hi = __builtin_fminf(by + ry - Yg, (float)(left - 1));
-        if (Yg == Yg && lo <= hi) {
-            first[g] = (int)__builtin_ceilf(lo);
-            const int n = (int)__builtin_floorf(hi) - first[g] + 1;
-            count[g] = n > 0 ? n : 0;
-        }
-        ny += count[g];
+    for (int r0 = 0; r0 < L::WH; r0 += 64) {
+        const int r = r0 + lane;
+        const bool in = r < L::WH && __builtin_fabsf(rows_y[r < L::WH ? r : 0] - by) <= ry;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+        if (in) row_list[ny + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = r;
+        ny += __builtin_popcountll(m);
     }
     if (ny == 0) return;
     const float4* __restrict__ g4 = A.planes + tri;
@@ -297,16 +290,10 @@ __device__ __forceinline__ void raster_rare_block(const SweepArgs& A, const floa
     const int npix = nx * ny;
     const float inv_nx = 1.0f / (float)nx;
     for (int k = lane; k < npix; k += 64) {
-        // (k + 1/2) / nx: the quotient's rounding stays far below 1 / (2 nx) for k < 2^18, nx <= 2^12
-        int r = (int)__builtin_floorf(((float)k + 0.5f) * inv_nx);
+        // (k + 1/2) / nx: the quotient's rounding stays far below 1 / (2 nx) for k < 2^20, nx <= 2^12
+        const int r = (int)__builtin_floorf(((float)k + 0.5f) * inv_nx);
         const int c = k - r * nx;
-        int row = 0;                    // local row within the block
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const bool here = r >= 0 && r < count[g];
-            row = here ? RT_TILE_H * g + first[g] + r : row;
-            r = here ? -1 : r - count[g];
-        }
+        const int row = row_list[r];        // local row within the block
         const int px = x_lo + c;
         finish_raster(A, (long)(wave_y0 + row) * A.W + px, tri, P, margin, Hh, N, (float)(px - A.W / 2) * (1.0f / COLS),
                       rows_y[row]);
@@ -316,7 +303,7 @@ __device__ __forceinline__ void raster_rare_block(const SweepArgs& A, const floa
 template <int R>
 __device__ __forceinline__ void raster_triangle_reg(const SweepArgs& A, const float4& box, int tri, float Xs0,
                                                     const float (&YG)[RasterGroups<R>::G], const float* rows_y,
-                                                    int wave_x0, int wave_y0, int lane)
+                                                    int* row_list, int wave_x0, int wave_y0, int lane)
 {
     using L = RasterLane<R>;
     constexpr int RX = L::RX, G = RasterGroups<R>::G, RG = RasterGroups<R>::RG;
@@ -362,17 +349,12 @@ __device__ __forceinline__ void raster_triangle_reg(const SweepArgs& A, const fl
                 for (int j = 0; j < RG; ++j) {
                     const int lrow = lane / L::SX + RT_TILE_H * g + L::SY * j;       // local row within the block
                     if (!(__builtin_fabsf(e[g] + KY * (float)j) <= box.w) || lr0 + RT_TILE_H * g + L::SY * j >= A.rows.rows) continue;
-                    const float Yg = rows_y[RT_TILE_H * g];
-                    int left = A.rows.rows - (wave_y0 + RT_TILE_H * g);
-                    left = left > RT_TILE_H ? RT_TILE_H : left;
-                    const float lo = __builtin_fmaxf(box.z - box.w - Yg, 0.0f), hi = __builtin_fminf(box.z + box.w - Yg, (float)(left - 1));
-                    const int in_g = lrow - RT_TILE_H * g;
-                    if (!(lo <= hi && in_g >= (int)__builtin_ceilf(lo) && in_g <= (int)__builtin_floorf(hi))) ++missed;
+                    if (!(__builtin_fabsf(rows_y[lrow] - box.z) <= box.w)) ++missed;      // the rare path's own row test
                 }
             if (missed && A.tests) atomicAdd(A.tests, missed << 48);
         }
 #endif
-        raster_rare_block<R>(A, box, tri, wave_x0, wave_y0, rows_y, lane);
+        raster_rare_block<R>(A, box, tri, wave_x0, wave_y0, rows_y, row_list, lane);
     }
 }
 
@@ -464,6 +446,7 @@ k_sweep_raster(const SweepArgs A)
     // driver.c:132 per local row of the wave, in LDS, for the rare path (which indexes it by a row
     // number of its own in every lane); NaN for a row beyond the band
     __shared__ float row_y[RT_WG / 64][WH];
+    __shared__ int row_list[RT_WG / 64][REG ? WH : 1];     // the rare path's list of a box's rows (regular-row form)
     constexpr int NY = REG ? 1 : RY, NG = REG ? RasterGroups<R>::G : 1;
     float Y[NY];                                                    // every row of the lane's lattice, or ...
     float YG[NG];                                                   // ... the first one of every 16-row group
@@ -562,7 +545,7 @@ k_sweep_raster(const SweepArgs A)
                         const float4 box = next;
                         next = lds_read_float4(box_at + 16u * (unsigned)(k + 1));
                         if constexpr (REG)
-                            raster_triangle_reg<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, YG, row_y[wave], wave_x0, wave_y0, lane);
+                            raster_triangle_reg<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, YG, row_y[wave], row_list[wave], wave_x0, wave_y0, lane);
                         else
                             raster_triangle<R>(A, box, tri0 + sub * RT_TILE + j4 + k, Xs0, Y, y_of_row, px0, lr0, slot0);
                     }
@@ -1186,7 +1169,7 @@ void rt_raster_shape(int W, int rows, int tiles, bool regular, int* pixels_per_l
         const int n = sscanf(force, "%d,%d,%d", &fr, &fc, &fw);
         if (n >= 2 && fc >= 1 && fc <= (tiles < 1 ? 1 : tiles) &&
             (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == 16 || fr == 32 || fr == 64 || fr == 128 || fr == 256 ||
-             fr == 512 || fr == 1024 || fr == 2048 || fr == 4096) &&
+             fr == 512 || fr == 1024 || fr == 2048 || fr == 4096 || fr == 8192 || fr == 16384) &&
             fr <= rpl_max) {
             *pixels_per_lane = fr;
             *chunks = fc;
@@ -1197,18 +1180,22 @@ void rt_raster_shape(int W, int rows, int tiles, bool regular, int* pixels_per_l
     // (with tile culling a wave's pixel rectangle should not be too wide: the narrower, the fewer
     // triangles survive its test; 32 pixels per lane measured best on a 1 M-triangle 4K frame)
     int r = rt_tile_culling() && RT_RASTER_RPL > 32 ? 32 : rpl_max;
-    // The wider a wave's pixels (a lane of 1024 pixels has 64 columns of 16 rows: the wave is
-    // 4096 pixels wide), the fewer instructions a pair costs, and the more often the wave has a
-    // pixel inside a triangle's box and its lanes walk their columns and rows in the rare path.
-    // How often depends on the size of the triangles on the screen, for which their number
-    // stands in: measured at 3840x2160, a million triangles sweep in 12.7 ms with 2048 pixels per
-    // lane (64 columns of 32 rows: the wave is 4096 x 32 pixels and the kernel needs 80 registers),
-    // 17.4 with 1024, 20.6 with 512 and 27.5 with 256; 100 000 in 3.4 (1024), 2.7 and 3.9 ms (4.3
-    // with 128); 69 000 in 3.3, 3.2 and 3.6; 6 000 fastest with 128.
-    static const int rows64_tiles = getenv("RT_AMD_RASTER_ROWS64_TILES") ? atoi(getenv("RT_AMD_RASTER_ROWS64_TILES")) : 4096;
-    // (128 rows per lane were measured too: 10.1 ms against 9.6 for a million triangles at 3840x2160
-    // with 1024 chunks, 9.45 against 8.96 with 2048: the taller wave enters the rare path too often)
-    const int widest = tiles >= rows64_tiles ? 4096 : (tiles >= 4096 ? 2048 : (tiles >= 256 ? 512 : 128));
+    // The wider and taller a wave's pixels (a lane of 1024 pixels has 64 columns of 16 rows, the wave
+    // is 4096 x 16 pixels; a lane of 16384 has 256 rows), the fewer instructions a pair costs, and
+    // the more often the wave has a pixel inside a triangle's box and enters the rare path.  How
+    // often depends on the size of the triangles on the screen, for which their number stands in.
+    // In the regular-row form the wave walks a passing box's pixels together and the rare path is
+    // cheap; measured at 3840x2160: a million triangles sweep in 7.1 ms with 4096 pixels per lane,
+    // 5.6 with 8192, 5.1 with 16384; 100 000 (a torus) in 2.16 ms with 512, 1.75 (1024), 1.11 (2048),
+    // 0.85 (4096), 0.88 (8192), 0.96 (16384); 69 000 (a sphere) in 1.67 (512), 0.98 (2048), 0.88 (4096),
+    // 0.90 (8192); 6 000 in 0.56 (128), 0.50 (512), 0.57 (1024), 0.95 (2048).  In the other forms every
+    // lane walks its own columns and rows: a million triangles in 12.7 ms with 2048 pixels per lane,
+    // 17.4 with 1024, 20.6 with 512; 100 000 in 3.4 (1024), 2.7 (512), 3.9 ms (256); 6 000 fastest with 128.
+    static const int rows256_tiles = getenv("RT_AMD_RASTER_ROWS256_TILES") ? atoi(getenv("RT_AMD_RASTER_ROWS256_TILES")) : 4096;
+    static const int rows64_tiles = getenv("RT_AMD_RASTER_ROWS64_TILES") ? atoi(getenv("RT_AMD_RASTER_ROWS64_TILES")) : 256;
+    const int widest = rpl_max > RT_RASTER_RPL
+                           ? (tiles >= rows256_tiles ? 16384 : tiles >= rows64_tiles ? 4096 : tiles >= 32 ? 1024 : 128)
+                           : (tiles >= 4096 ? 2048 : (tiles >= 256 ? 512 : 128));
     if (r > widest) r = widest;
     while (r > 1 && rt_raster_wave_cols(r) > W + rt_raster_wave_cols(r) / 2) r /= 2;    // no wave mostly off the image
     // more pixels per lane cost fewer instructions per pair, but their wider tiles may cover
@@ -1276,6 +1263,8 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
                       : (regular ? launch(k_sweep_raster<n, false, true>, a, grid, st, "raster sweep")     \
                                  : launch(k_sweep_raster<n, false, false>, a, grid, st, "raster sweep"));
     if (r == 4096 && regular && !a.cull) return launch(k_sweep_raster<4096, false, true>, a, grid, st, "raster sweep");
+    if (r == 8192 && regular && !a.cull) return launch(k_sweep_raster<8192, false, true>, a, grid, st, "raster sweep");
+    if (r == 16384 && regular && !a.cull) return launch(k_sweep_raster<16384, false, true>, a, grid, st, "raster sweep");
     switch (r) {
         RT_RASTER_CASE(1)
         RT_RASTER_CASE(2)
