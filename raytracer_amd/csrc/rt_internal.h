@@ -150,6 +150,7 @@ struct rt_scene {
     DevBuf planes;
     // same for the apex sweeps: RT_APEX_PLANES planes, repacked for the eye and for each light
     DevBuf planes_apex, tri_order;
+    bool lights_sorted = false;     // whether the current lights' planes are in tri_order's order (else: triangle order)
     // ... and for the lights of one any-hit launch (RT_APEX_LIGHTS sets side by side), sorted and
     // packed on a side stream while the primary sweep runs
     DevBuf planes_light, ws_sort_tri;
@@ -385,7 +386,7 @@ int rt_launch_compact(const int32_t* cnt, const int32_t* in, const int* in_count
 struct CellSet {
     int light, axis;        // of the launch's group of lights; dominant axis 0..2
     int gu_log2, gv_log2;   // the set's grid: 2^gu columns (u) by 2^gv rows (v)
-    int cell_base;          // first entry of the set in the cell table
+    int cell_base;          // the set's first cell among the launch's cells (its first table entry: cell_base << 2 fine_log2)
     int fp_base;            // first footprint (the block of cells one wave owns) of the set
     int fp_cols_log2;       // footprints side by side in a row of the grid
     int ray_base, rays;     // the set's rays in the launch's sorted arrays (host's count)
@@ -399,8 +400,10 @@ struct CellArgs {
     long plane_stride, light_plane_stride;
     int num_tris_padded;
     int tri_begin, tri_end; // tile-aligned
-    const int* table;       // cells + 1 entries: rays in the cells before this one; the rays of cell c are rays[table[c] .. table[c + 1])
-    float2* rays;           // sorted by cell: (u, v); u = NaN once the ray has retired
+    int fine_log2;          // every cell is cut into 2^fine x 2^fine fine cells: the grid the rays are sorted and looked up by
+    const int* table;       // fine cells + 1 entries: rays in the fine cells before this one (a set's fine cells row by row
+                            // over its whole grid); the rays of fine cell c are rays[table[c] .. table[c + 1])
+    float2* rays;           // sorted by fine cell: (u, v); u = NaN once the ray has retired
     const float2* len_sig;  // same order: |light - S| and 1 / (unit direction)_k, for the rare path's ray parameter
     const int32_t* slot;    // the ray's entry in cnt / list / occ_id
     int32_t *cnt, *list, *occ_id;
@@ -414,6 +417,7 @@ struct CellPlan {
     int cells_per_lane;     // 2048, 512, 128 or 32: the kernel shape
     int chunks;             // triangle chunks (blockIdx.y)
     long cells, footprints, rays;
+    int fine_log2;          // = args.fine_log2
     const int* wide;        // per set: the triangles swept ray by ray instead (k_cell_boxes)
     int largest_set;        // rays of the largest set
 };

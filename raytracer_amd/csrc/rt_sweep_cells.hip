@@ -37,7 +37,7 @@
 #define RT_CELLS_UNROLL 4
 #endif
 #ifndef RT_CELLS_GROUP
-#define RT_CELLS_GROUP 4    // tiles of boxes staged at a time
+#define RT_CELLS_GROUP 2    // tiles of boxes staged at a time
 #endif
 
 namespace {
@@ -60,7 +60,7 @@ struct CellCtx {
     const float4* planes;   // of the set's light
     long plane_stride;
     long square_plane;      // the plane of that light's squares for the set's axis
-    int axis, gu_log2, cell_base;
+    int axis, gu_log2, cell_base, fine_log2;
     const int32_t* tri_order;   // of the set's light, or nullptr
 };
 
@@ -137,20 +137,39 @@ __device__ __forceinline__ int wave_search(int incl, int r)
 template <int R>
 __device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, const float4* qbox, int tri0,
                                            unsigned passed, int fx0, int fy0, float su, float sv, int lane,
-                                           unsigned& tested, unsigned& visited)
+                                           float4 (*qplanes)[3], unsigned& tested, unsigned& visited)
 {
     using L = CellLane<R>;
     // lane k: the rectangle of triangle k (no rows when the triangle did not pass, or the box
-    // misses the footprint after all)
+    // misses the footprint after all), and the triangle's planes on their way into LDS (qplanes:
+    // the components in the order of the set's axis, D' . p = u p0 + v p1 + p2, as three records
+    // (P, margin), (H, Hw), (N, en)), so that the tests below wait for memory once per quarter tile
+    // and not once per batch of rays
     int x_lo = 0, nx = 0, y_lo = 0, ny = 0;
-    if (lane < 32 && ((passed >> lane) & 1u)) {
+    const int fl = X.fine_log2;
+    const float F = (float)(1 << fl);
+    const int ax = X.axis;
+    const bool mine = lane < 32 && ((passed >> lane) & 1u);
+    float4 P, Hh, N;
+    float margin = 0.0f;
+    if (mine) {
+        const float4* __restrict__ g = X.planes + (tri0 + lane);
+        P = g[0];
+        margin = g[X.plane_stride].w;
+        Hh = g[2 * X.plane_stride];
+        N = g[3 * X.plane_stride];
         const float4 box = qbox[lane];
-        // The cells to visit: integer centres x with |x - cx| <= rho hu + 1/2 for the exact centre
-        // and extent.  The stored extent exceeds that by 2^-9 cell, more than the roundings of the
-        // stored centre and of the two bounds here, so the integers between the computed bounds
-        // include them.
-        const float xl = __builtin_fmaxf(box.x - box.y, (float)fx0), xh = __builtin_fminf(box.x + box.y, (float)(fx0 + L::WW - 1));
-        const float yl = __builtin_fmaxf(box.z - box.w, (float)fy0), yh = __builtin_fminf(box.z + box.w, (float)(fy0 + L::WH - 1));
+        // The fine cells to visit.  A fine cell's centre has the coordinate j in fine units,
+        // (j + 1/2) / F - 1/2 in cell units; its rays lie within half a fine cell of it, so the fine
+        // cells that can hold a ray of the square are the integers j with |j - xc| <= rho hu F + 1/2,
+        // xc = (cx + 1/2) F - 1/2.  The stored extent is rho hu + 1/2 + 2^-9 (cell units): the 2^-9 F
+        // fine cells left over exceed the roundings of the stored centre, of xc and of the two bounds
+        // here (each at most F 2^-13 on coordinates below 4096 F), so the integers between the
+        // computed bounds include them.
+        const float xc = __builtin_fmaf(box.x, F, 0.5f * F - 0.5f), hx = __builtin_fmaf(box.y - 0.5f, F, 0.5f);
+        const float yc = __builtin_fmaf(box.z, F, 0.5f * F - 0.5f), hy = __builtin_fmaf(box.w - 0.5f, F, 0.5f);
+        const float xl = __builtin_fmaxf(xc - hx, (float)(fx0 << fl)), xh = __builtin_fminf(xc + hx, (float)(((fx0 + L::WW) << fl) - 1));
+        const float yl = __builtin_fmaxf(yc - hy, (float)(fy0 << fl)), yh = __builtin_fminf(yc + hy, (float)(((fy0 + L::WH) << fl) - 1));
         if (xl <= xh && yl <= yh) {
             x_lo = (int)__builtin_ceilf(xl);
             y_lo = (int)__builtin_ceilf(yl);
@@ -162,8 +181,14 @@ __device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, 
     const int rows_incl = wave_scan(ny, lane);
     const int rows_total = __builtin_amdgcn_readlane(rows_incl, 63);
     const int rows_excl = rows_incl - ny;
-    const int* __restrict__ table = A.table + X.cell_base;
-    const int ax = X.axis;
+    if (rows_total == 0) return;
+    if (mine) {
+        // dot_ax of rt_sweep_apex.hip: D' = (1, u, v), (u, 1, v) or (u, v, 1)
+        qplanes[lane][0] = make_float4(ax == 0 ? P.y : P.x, ax == 2 ? P.y : P.z, ax == 0 ? P.x : (ax == 1 ? P.y : P.z), margin);
+        qplanes[lane][1] = make_float4(ax == 0 ? Hh.y : Hh.x, ax == 2 ? Hh.y : Hh.z, ax == 0 ? Hh.x : (ax == 1 ? Hh.y : Hh.z), Hh.w);
+        qplanes[lane][2] = make_float4(ax == 0 ? N.y : N.x, ax == 2 ? N.y : N.z, ax == 0 ? N.x : (ax == 1 ? N.y : N.z), N.w);
+    }
+    const int* __restrict__ table = A.table + ((long)X.cell_base << (2 * fl));
     const float qnan = __builtin_nanf("");
     for (int p0 = 0; p0 < rows_total; p0 += 64) {
         // this lane's (triangle, row) pair
@@ -173,7 +198,7 @@ __device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, 
         const int ex = __shfl(x_lo, e), enx = __shfl(nx, e), ey = __shfl(y_lo, e);
         int first = 0, n = 0;
         if (p < rows_total) {
-            const int at = ((ey + j) << X.gu_log2) + ex;
+            const int at = ((ey + j) << (X.gu_log2 + fl)) + ex;
             first = table[at];
             n = table[at + enx] - first;        // (behind a row's last cell comes the next row's first; the table has one more entry than cells)
             ++visited;
@@ -181,13 +206,29 @@ __device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, 
         const int rays_incl = wave_scan(n, lane);
         const int rays_total = A.debug_skip == 2 ? 0 : __builtin_amdgcn_readlane(rays_incl, 63);
         const int rays_excl = rays_incl - n;
-        for (int r0 = 0; r0 < rays_total; r0 += 64) {
+        // the ray of lane `lane` in the batch from r0 on: its number and its pair's triangle
+        auto deal = [&](int r0, int& i, int& k) {
             const int r = r0 + lane;
             const int q = wave_search(rays_incl, r);        // the pair whose run holds ray r
-            const int i = __shfl(first, q) + (r - __shfl(rays_excl, q));
-            const int k = __shfl(e, q);                     // ... and its triangle
-            if (r < rays_total) {
-                const float2 rec = A.rays[i];
+            i = __shfl(first, q) + (r - __shfl(rays_excl, q));
+            k = __shfl(e, q);
+        };
+        // (the next batch's rays are fetched while this batch is tested)
+        int i_next = 0, k_next = 0;
+        float2 rec_next = make_float2(qnan, 0.0f);
+        if (rays_total > 0) {
+            deal(0, i_next, k_next);
+            if (lane < rays_total) rec_next = A.rays[i_next];
+        }
+        for (int r0 = 0; r0 < rays_total; r0 += 64) {
+            const int i = i_next, k = k_next;
+            const float2 rec = rec_next;
+            const bool live = r0 + lane < rays_total;
+            if (r0 + 64 < rays_total) {
+                deal(r0 + 64, i_next, k_next);
+                rec_next = r0 + 64 + lane < rays_total ? A.rays[i_next] : make_float2(qnan, 0.0f);
+            }
+            if (live) {
                 const float4 box = qbox[k];
                 ++tested;
                 // The ray against the triangle's square, in cell units: the box less the half cell it
@@ -196,15 +237,9 @@ __device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, 
                 const float xr = __builtin_fmaf(rec.x, su, su - 0.5f), yr = __builtin_fmaf(rec.y, sv, sv - 0.5f);
                 if (__builtin_fabsf(xr - box.x) <= box.y - 0.5f && __builtin_fabsf(yr - box.z) <= box.w - 0.5f &&
                     A.debug_skip != 3) {
-                    const int tri = tri0 + k;
-                    const float4* __restrict__ g = X.planes + tri;
-                    const float4 P = g[0], Hh = g[2 * X.plane_stride], N = g[3 * X.plane_stride];
-                    const float margin = g[X.plane_stride].w;
-                    // dot_ax of rt_sweep_apex.hip: D' = (1, u, v), (u, 1, v) or (u, v, 1)
-                    const float Pp[3] = {ax == 0 ? P.y : P.x, ax == 2 ? P.y : P.z, ax == 0 ? P.x : (ax == 1 ? P.y : P.z)};
-                    const float Hp[3] = {ax == 0 ? Hh.y : Hh.x, ax == 2 ? Hh.y : Hh.z, ax == 0 ? Hh.x : (ax == 1 ? Hh.y : Hh.z)};
-                    const float Np[3] = {ax == 0 ? N.y : N.x, ax == 2 ? N.y : N.z, ax == 0 ? N.x : (ax == 1 ? N.y : N.z)};
-                    if (finish_cell(A, X, rec, i, tri, Pp, margin, Hp, Hh.w, Np, N.w)) A.rays[i].x = qnan;
+                    const float4 p0 = qplanes[k][0], p1 = qplanes[k][1], p2 = qplanes[k][2];
+                    const float Pp[3] = {p0.x, p0.y, p0.z}, Hp[3] = {p1.x, p1.y, p1.z}, Np[3] = {p2.x, p2.y, p2.z};
+                    if (finish_cell(A, X, rec, i, tri0 + k, Pp, p0.w, Hp, p1.w, Np, p2.w)) A.rays[i].x = qnan;
                 }
             }
         }
@@ -259,6 +294,7 @@ k_sweep_cells(const CellArgs A)
     // (one more entry: the read-ahead touches the one behind the second buffer)
     __shared__ float4 tile_lds[2 * kGroup * RT_TILE + 1];
     auto tile = reinterpret_cast<float4 (*)[kGroup * RT_TILE]>(tile_lds);
+    __shared__ float4 plane_lds[RT_WG / 64][RT_TILE / 4][3];       // the rare path's planes of a quarter tile, per wave
     using L = CellLane<R>;
 
     const int tid = threadIdx.x;
@@ -277,6 +313,7 @@ k_sweep_cells(const CellArgs A)
     X.axis = cs.axis;
     X.gu_log2 = cs.gu_log2;
     X.cell_base = cs.cell_base;
+    X.fine_log2 = A.fine_log2;
     X.tri_order = A.tri_order ? A.tri_order + (long)cs.light * A.num_tris_padded : nullptr;
 
     const int f = (int)blockIdx.x - cs.fp_base;
@@ -329,7 +366,7 @@ k_sweep_cells(const CellArgs A)
             }
             if (__builtin_expect(passed != 0, 0)) {
                 entered += __builtin_popcount(passed);
-                if (A.debug_skip != 1) cells_rare<R>(A, X, qbox, tri0, passed, fx0, fy0, su, sv, lane, tested, visited);
+                if (A.debug_skip != 1) cells_rare<R>(A, X, qbox, tri0, passed, fx0, fy0, su, sv, lane, plane_lds[wave], tested, visited);
             }
         }
         __builtin_amdgcn_s_waitcnt(0);
@@ -353,6 +390,7 @@ k_sweep_cells(const CellArgs A)
 struct CellKeySets {
     CellSet set[RT_APEX_SETS];
     int sets;
+    int fine_log2;
 };
 
 // blockIdx.y = set.  Ray i of the set: its (u, v) and (len, sig) exactly as k_sweep_apex forms
@@ -368,8 +406,11 @@ k_cell_keys(const double* __restrict__ S, const double* __restrict__ E, const in
     const long ray0 = (long)cs.light * stride;
     const int32_t* ids = lists + (long)cs.list * stride;
     const float qnan = __builtin_nanf("");
-    const float hu = (float)(1 << (cs.gu_log2 - 1)), hv = (float)(1 << (cs.gv_log2 - 1));    // cells per unit
-    const int gu = 1 << cs.gu_log2, gv = 1 << cs.gv_log2;
+    // the grid of fine cells (a cell is 2^fine x 2^fine of them, so a ray's cell is its fine cell's)
+    const int fl = ks.fine_log2;
+    const float hu = (float)(1 << (cs.gu_log2 + fl - 1)), hv = (float)(1 << (cs.gv_log2 + fl - 1));    // fine cells per unit
+    const int gu = 1 << (cs.gu_log2 + fl), gv = 1 << (cs.gv_log2 + fl);
+    const unsigned key_base = (unsigned)cs.cell_base << (2 * fl);
     for (int i = blockIdx.x * RT_WG + threadIdx.x; i < cs.rays; i += gridDim.x * RT_WG) {
         const long sl = ray0 + ids[i];
         const double* s = S + 3 * sl;
@@ -383,14 +424,14 @@ k_cell_keys(const double* __restrict__ S, const double* __restrict__ E, const in
         const double du = (axis == 0 ? D[1] : D[0]), dv = (axis == 2 ? D[1] : D[2]);
         float u = (float)(du / dk), v = (float)(dv / dk);
         if (!(u == u) || !(v == v)) valid = false;
-        // cell: u * 2^(gu-1) is exact in fp32, and so are the floor and the integer offset; u = 1
-        // belongs to the last cell (its distance from that cell's centre is half a cell exactly)
+        // fine cell: u * 2^(gu+fine-1) is exact in fp32, and so are the floor and the integer offset;
+        // u = 1 belongs to the last one (its distance from that one's centre is half of it exactly)
         int col = valid ? (int)__builtin_floorf(u * hu) + gu / 2 : 0;
         int row = valid ? (int)__builtin_floorf(v * hv) + gv / 2 : 0;
         col = col < 0 ? 0 : (col > gu - 1 ? gu - 1 : col);
         row = row < 0 ? 0 : (row > gv - 1 ? gv - 1 : row);
         const long g = cs.ray_base + i;
-        keys[g] = (unsigned)(cs.cell_base + (row << cs.gu_log2) + col);
+        keys[g] = key_base + (unsigned)((row << (cs.gu_log2 + fl)) + col);
         vals[g] = (int32_t)g;
         rec[g] = make_float2(valid ? u : qnan, v);
         len_sig[g] = make_float2((float)len, (float)sig);
@@ -486,6 +527,7 @@ k_cells_wide(const CellArgs A, const int* __restrict__ wide)
     X.axis = cs.axis;
     X.gu_log2 = cs.gu_log2;
     X.cell_base = cs.cell_base;
+    X.fine_log2 = A.fine_log2;
     X.tri_order = A.tri_order ? A.tri_order + (long)cs.light * A.num_tris_padded : nullptr;
     const int ax = cs.axis;
     const float qnan = __builtin_nanf("");
@@ -546,8 +588,14 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     // RT_AMD_CELLS_PER_RAY: cells per ray of a set's grid; RT_AMD_CELLS_FORCE="<cells per lane>[,<chunks>]"
     // (read at every call: tests run every kernel shape on small inputs)
     const char* cpr_env = getenv("RT_AMD_CELLS_PER_RAY");
-    double cells_per_ray = cpr_env ? atof(cpr_env) : 0.5;
-    if (!(cells_per_ray > 0)) cells_per_ray = 0.5;
+    double cells_per_ray = cpr_env ? atof(cpr_env) : 0.008;
+    if (!(cells_per_ray > 0)) cells_per_ray = 0.008;
+    // RT_AMD_CELLS_FINE: fine cells per ray -- the grid the rays are sorted into and looked up by in
+    // the rare path (every cell of the lattice is 4^fine fine cells; the rays the rare path tests
+    // against a triangle are those of the fine cells its square touches)
+    const char* fine_env = getenv("RT_AMD_CELLS_FINE");
+    double fine_per_ray = fine_env ? atof(fine_env) : 1.0;
+    if (!(fine_per_ray > 0)) fine_per_ray = 1.0;
     // RT_AMD_CELLS_WIDE: cells a triangle's box may cover before it is swept ray by ray instead
     // (default: an eighth of a wave's footprint, at least 4096 -- the ray-by-ray kernel costs a
     // test per ray of the set and triangle, so it is only for the few boxes whose rays one wave
@@ -595,44 +643,62 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
         p.rays = rays;
         p.cells_per_lane = r;
     };
+    // The launch has footprints x chunks workgroups, and a chunk is at least kGroup tiles long: a
+    // mesh of few triangles on a coarse grid would leave most of the machine idle (69 000
+    // triangles are 271 chunks; with 5 footprints 8.9 ms a frame at 3840x2160, with 40 6.2 ms).
+    // The grid is refined until the launch has about three rounds of workgroups.
+    const int tiles = np / RT_TILE;
+    const long max_chunks = tiles < 1 ? 1 : (tiles > 1024 ? 1024 : tiles);
+    const long enough_wgs = 8L * rt_device_cus();
     CellPlan best{};
-    double best_cost = -1;
-    for (int r : shapes) {
-        if (forced_r && r != forced_r) continue;
-        CellPlan p{};
-        layout(r, p);
-        const double cost = (double)p.cells * rt_cells_instr(r) / r;
-        if (best_cost < 0 || cost < best_cost) {
-            best = p;
-            best_cost = cost;
+    for (int refine = 0; refine < 8; ++refine) {
+        double best_cost = -1;
+        for (int r : shapes) {
+            if (forced_r && r != forced_r) continue;
+            CellPlan p{};
+            layout(r, p);
+            const double cost = (double)p.cells * rt_cells_instr(r) / r;
+            if (best_cost < 0 || cost < best_cost) {
+                best = p;
+                best_cost = cost;
+            }
         }
+        if (cpr_env || best.rays == 0 || best.footprints * max_chunks >= enough_wgs || cells_per_ray >= 1.0) break;
+        cells_per_ray *= 4.0;
     }
     *plan = best;
     if (plan->rays == 0) return RT_OK;
+    {
+        int fl = 0;
+        while (fl < 8 && (double)(plan->cells << (2 * (fl + 1))) <= fine_per_ray * (double)plan->rays * 2.0 &&
+               (plan->cells << (2 * (fl + 1))) < (1L << 28))
+            ++fl;
+        for (int k = 0; k < plan->args.sets; ++k)           // (coordinates in fine cells stay below 2^16)
+            while (fl > 0 && (plan->args.set[k].gu_log2 + fl > 16 || plan->args.set[k].gv_log2 + fl > 16)) --fl;
+        plan->fine_log2 = plan->args.fine_log2 = fl;
+    }
+    const long fine_cells = plan->cells << (2 * plan->fine_log2);
     if (!(wide_cells > 0.0f)) {
         wide_cells = (float)(rt_cells_wave_cols(plan->cells_per_lane) * rt_cells_wave_rows(plan->cells_per_lane) / 8);
         if (wide_cells < 4096.0f) wide_cells = 4096.0f;
     }
-    if (plan->cells >= (1L << 30) || plan->rays >= (1L << 31)) {
+    if (fine_cells >= (1L << 30) || plan->rays >= (1L << 31)) {
         rt_set_error("cell sweep: too many cells or rays for one launch");
         return RT_E_LIMIT;
     }
     const int n = (int)plan->rays;
-    const int tiles = np / RT_TILE;
     // triangle chunks: about 24 rounds of workgroups, a chunk at least one group of tiles long
     {
         const long slots = 8L * rt_device_cus();
         long c = (24 * slots + plan->footprints - 1) / plan->footprints;
-        const long max_chunks = tiles / kGroup < 1 ? 1 : tiles / kGroup;
         if (c > max_chunks) c = max_chunks;
-        if (c > 1024) c = 1024;
         if (forced_chunks) c = forced_chunks > tiles ? tiles : forced_chunks;
         plan->chunks = c < 1 ? 1 : (int)c;
     }
 
     // workspace: sort keys and values (in, out), records and slots (by ray, by cell), rocPRIM's own
     unsigned key_bits = 1;
-    while ((1L << key_bits) < plan->cells) ++key_bits;
+    while ((1L << key_bits) < fine_cells) ++key_bits;
     size_t temp_bytes = 0;
     if (rocprim::radix_sort_pairs(nullptr, temp_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (int32_t*)nullptr,
                                   (int32_t*)nullptr, (unsigned)n, 0u, key_bits, st) != hipSuccess) {
@@ -641,7 +707,7 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     }
     const size_t a4 = ((size_t)n * 4 + 255) & ~(size_t)255, a8 = ((size_t)n * 8 + 255) & ~(size_t)255;
     RT_TRY(sc->ws_cell_rays.reserve(6 * a4 + 4 * a8 + temp_bytes));
-    RT_TRY(sc->ws_cell_table.reserve(sizeof(int) * ((size_t)plan->cells + 1)));
+    RT_TRY(sc->ws_cell_table.reserve(sizeof(int) * ((size_t)fine_cells + 1)));
     RT_TRY(sc->ws_cell_boxes.reserve(sizeof(float4) * (size_t)np * plan->args.sets));
     RT_TRY(sc->ws_cell_wide.reserve(sizeof(int) * (RT_CELLS_WIDE_CAP + 1) * RT_APEX_SETS));
     RT_HIP(hipMemsetAsync(sc->ws_cell_wide.p, 0, sizeof(int) * (RT_CELLS_WIDE_CAP + 1) * RT_APEX_SETS, st));
@@ -660,6 +726,7 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
 
     CellKeySets ks{};
     ks.sets = plan->args.sets;
+    ks.fine_log2 = plan->fine_log2;
     int largest = 0;
     for (int k = 0; k < ks.sets; ++k) {
         ks.set[k] = plan->args.set[k];
@@ -675,8 +742,8 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     hipLaunchKernelGGL(k_cell_gather, dim3((unsigned)((n + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0, st, vals_out, n,
                        rec_in, ls_in, slot_in, rec, ls, slot);
     RT_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_cell_table, dim3((unsigned)((plan->cells + 1 + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0, st,
-                       keys_out, n, (int)plan->cells, sc->ws_cell_table.as<int>());
+    hipLaunchKernelGGL(k_cell_table, dim3((unsigned)((fine_cells + 1 + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0, st,
+                       keys_out, n, (int)fine_cells, sc->ws_cell_table.as<int>());
     RT_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_cell_boxes, dim3((unsigned)((np + RT_WG - 1) / RT_WG), ks.sets), dim3(RT_WG), 0, st, a.planes,
                        a.plane_stride, a.light_plane_stride, np, ks, wide_cells, sc->ws_cell_boxes.as<float4>(),
