@@ -418,28 +418,38 @@ def main() -> None:
         sh_ms, sh_tests = prof.shadow_ms, float(prof.shadow_tests)
         sh_rate = sh_tests / (sh_ms * 1e-3) if sh_ms > 0 else 0.0
         if prof.cell_launches > 0:
-            # sweeps over lattices of direction cells: the hot loop executes one separable test per
+            # Sweeps over lattices of direction cells.  The hot loop executes one separable test per
             # (cell, triangle) pair -- an addition per column and per row of a lane's lattice, a
-            # three-way minimum per two of either, two compares -- and the rare path tests the rays
-            # of a passing cell one by one
+            # three-way minimum per two of either, two compares.  The library keeps the lattice
+            # coarse (a few footprints per set of rays), so that loop only tells which triangles come
+            # near a wave's footprint; behind it the rays of the fine cells a triangle's square
+            # touches are looked up (a prefix table over the sorted rays) and tested one by one,
+            # and that part -- dependent gathers, not arithmetic -- is what the launch's time is.
             cpl = int(prof.cells_per_lane)
             c_rows = {2048: 32, 512: 16, 128: 8, 32: 4, 8: 2}[cpl]
             c_cols = cpl // c_rows
             c_instr = (c_cols + c_rows + c_cols // 2 + c_rows // 2 + 2) / cpl
             c_flop = (c_cols + c_rows) / cpl
             c_rate = prof.cell_pairs / (prof.cell_ms * 1e-3) if prof.cell_ms > 0 else 0.0
+            one_by_one = float(prof.cell_ray_pairs)
             rp_sh = rocprof_avg_ms(args.workload, f"k_sweep_cells<{cpl}>") if world == 1 else None
             anyhit = {
-                "kernel": f"k_sweep_cells<{cpl}> (shadow rays, any hit: every cell of a lattice of directions against "
-                          "every triangle, the rays of a passing cell one by one)",
+                "kernel": f"k_sweep_cells<{cpl}> (shadow rays, any hit: every cell of a coarse lattice of directions "
+                          "against every triangle, then the rays of the fine cells a triangle's square touches one by one)",
+                "bound": "latency of the rare path's gathers (row look-ups, rays, candidate records); the hot loop is "
+                         "a small part of the launch at this lattice size",
                 "ms_per_frame": sh_ms, "share_of_step": sh_ms / ms_step, "launches_per_frame": int(prof.shadow_launches),
                 "lattice_launches": int(prof.cell_launches), "ms_in_lattice_launches": prof.cell_ms,
                 "rays_swept": float(prof.cell_rays), "cell_pairs_per_frame": float(prof.cell_pairs),
-                "cell_pairs_per_s": c_rate, "ray_pairs_one_by_one_per_frame": float(prof.cell_ray_pairs),
+                "cell_pairs_per_s": c_rate,
+                "fine_cells_per_cell": int(prof.cell_fine),
+                "triangles_entering_rare_path_per_frame": float(prof.cell_entries),
                 "row_lookups_per_frame": float(prof.cell_lookups),
+                "ray_pairs_one_by_one_per_frame": one_by_one,
+                "ray_pairs_one_by_one_per_s": one_by_one / (prof.cell_ms * 1e-3) if prof.cell_ms > 0 else 0.0,
                 "tests_per_frame": sh_tests, "tests_per_s": sh_rate,
                 "test": "a (ray, triangle) pair decided: every listed ray against every triangle, most pairs through "
-                        "their cell's test",
+                        "their cell's test or through lying outside the fine cells a triangle's square touches",
                 "flop_per_cell_pair": c_flop, "achieved": c_rate * c_flop / 1e12, "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s", "frac": c_rate * c_flop / 1e12 / PEAK_FP32_TFLOPS,
                 "rocprof": rp_sh,
@@ -448,7 +458,7 @@ def main() -> None:
                                                          "logic": c_cols // 2 + c_rows // 2, "compare": 2},
                                "achieved": c_rate * c_instr / 1e12, "peak": PEAK_VALU_TINSTR, "unit": "T lane-instr/s",
                                "frac": c_rate * c_instr / 1e12 / PEAK_VALU_TINSTR,
-                               **mix_alone(f"raster{cpl}_box", c_rate)},
+                               "note": "hot loop only; see `bound`"},
                 "cells_per_lane": cpl,
             }
         else:

@@ -271,6 +271,8 @@ typedef struct rt_profile {
     uint64_t cell_rays;         /* rays swept that way */
     uint64_t cells_per_lane;    /* kernel shape of the most recent such launch */
     uint64_t cell_lookups;      /* cell-table look-ups of the rare path */
+    uint64_t cell_fine;         /* fine cells (the grid the rays are sorted and looked up by) per cell, most recent launch */
+    uint64_t cell_entries;      /* (wave footprint, triangle) pairs that went on to the rare path */
 } rt_profile;
 /* Compile-time shape of the sweep kernel for rays in general position (rt_trace_rays,
  * rt_occluded): formulation (2 = moment form), triangles per LDS tile, rays per lane, and the

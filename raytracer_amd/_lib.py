@@ -66,6 +66,8 @@ class RtProfile(C.Structure):
         ("cell_rays", C.c_uint64),
         ("cells_per_lane", C.c_uint64),
         ("cell_lookups", C.c_uint64),
+        ("cell_fine", C.c_uint64),
+        ("cell_entries", C.c_uint64),
     ]
 
 

@@ -688,6 +688,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     a.W = W; a.H = H; a.rows = rows;
     a.ez = ez;
     a.cnt = sc->ws_cnt.as<int32_t>(); a.list = sc->ws_list.as<int32_t>();
+    a.list_stride = (long)npix;         // slot-major lists: entry c of pixel p at list[c * npix + p]
     a.best_hi = sc->ws_besthi.as<float>();
     a.chunks = chunks;
     a.waves_x = waves_x;
@@ -721,7 +722,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
 
     const ExactScene es = exact_of(sc);
     int* counters = sc->ws_counters.as<int>();
-    RT_TRY(rt_launch_resolve_primary(es, W, H, tan_half, rows, a.cnt, a.list, hit, tuv, sc->ws_ovf.as<int32_t>(), counters, st));
+    RT_TRY(rt_launch_resolve_primary(es, W, H, tan_half, rows, a.cnt, a.list, a.list_stride, hit, tuv, sc->ws_ovf.as<int32_t>(), counters, st));
     RT_TRY(rt_launch_overflow_primary(es, W, H, tan_half, rows, sc->ws_ovf.as<int32_t>(), counters,
                                       hit, tuv, sc->ws_partials.p, st));
     RT_TRY(fetch_counters(counters, false));
@@ -954,6 +955,8 @@ static int anyhit_cells(rt_scene* sc, SweepArgs a, int sets, long stride, const 
     RT_HIP(hipStreamSynchronize(st));
     const unsigned long long t = tt[0];
     g.prof.cell_lookups += tt[2];
+    g.prof.cell_entries += tt[3];
+    g.prof.cell_fine = 1ull << (2 * plan.fine_log2);
     g.prof.shadow_ms += ms;
     g.prof.shadow_launches++;
     // pairs decided: every listed ray against every triangle; what the hot loop executes is one

@@ -95,12 +95,13 @@ struct Best {
 // over ascending triangle numbers and replaces its winner only on `dist > 0 && dist < t`
 // (triangle_intersection.cu:167-176), i.e. it keeps the smallest t and, among equal t, the lowest
 // triangle number: that is the rule applied here, whatever order the candidates were listed in.
-// Returns false when the list overflowed; ncand = candidates evaluated.
+// Returns false when the list overflowed; ncand = candidates evaluated.  Entry k of ray p is
+// list[p * K + k], or list[k * slot_major + p] when slot_major is not 0.
 template <bool ANYHIT, int K>
 __device__ __forceinline__ bool confirm_list(const ExactScene& es, const double S[3],
                                              const double E[3], const int32_t* __restrict__ cnt,
                                              const int32_t* __restrict__ list, long p, Best& best,
-                                             bool& occluded, int& ncand)
+                                             bool& occluded, int& ncand, long slot_major = 0)
 {
     best.t = 1e50;                  // triangle_intersection.cu:108
     best.idx = -1;
@@ -115,9 +116,10 @@ __device__ __forceinline__ bool confirm_list(const ExactScene& es, const double 
     n &= RT_CNT_MASK;
     if (n > K) return false;
     ncand = n;
-    const int32_t* l = list + p * K;
+    const int32_t* l = slot_major ? list + p : list + p * K;
+    const long step = slot_major ? slot_major : 1;
     for (int k = 0; k < n; ++k) {
-        const int i = l[k];
+        const int i = l[k * step];
         double u, v;
         const double dist = exact_tri(es, i, S, E, u, v);
         if ((dist > 0) && (dist < best.t || (dist == best.t && i < best.idx))) {       // :169
@@ -146,7 +148,7 @@ constexpr int RESOLVE_GRID = 4096;      // grid-stride: workgroups of the resolv
 
 __global__ void __launch_bounds__(RT_WG)
 k_resolve_primary(ExactScene es, int W, int H, double tan_half, RowMap rows,
-                  const int32_t* __restrict__ cnt, const int32_t* __restrict__ list,
+                  const int32_t* __restrict__ cnt, const int32_t* __restrict__ list, long list_stride,
                   int32_t* __restrict__ hit, double* __restrict__ tuv,
                   int32_t* __restrict__ ovf, int* __restrict__ counters)
 {
@@ -159,7 +161,7 @@ k_resolve_primary(ExactScene es, int W, int H, double tan_half, RowMap rows,
         Best b;
         bool occ;
         int ncand;
-        if (!confirm_list<false, RT_RASTER_LIST_K>(es, S, E, cnt, list, p, b, occ, ncand)) {
+        if (!confirm_list<false, RT_RASTER_LIST_K>(es, S, E, cnt, list, p, b, occ, ncand, list_stride)) {
             ovf[atomicAdd(&counters[0], 1)] = (int32_t)p;
         } else {
             total += ncand;
@@ -495,7 +497,7 @@ constexpr int SINGLE_RAY_GRID = 256;
 }  // namespace
 
 int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_half, const RowMap& rows,
-                              const int32_t* cnt, const int32_t* list,
+                              const int32_t* cnt, const int32_t* list, long list_stride,
                               int32_t* hit, double* tuv, int32_t* ovf, int* counters, hipStream_t st)
 {
     const long npix = (long)W * rows.rows;
@@ -503,7 +505,7 @@ int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_hal
     long wgs = (npix + RT_WG - 1) / RT_WG;
     if (wgs > RESOLVE_GRID) wgs = RESOLVE_GRID;
     hipLaunchKernelGGL(k_resolve_primary, dim3((unsigned)wgs), dim3(RT_WG),
-                       0, st, es, W, H, tan_half, rows, cnt, list, hit, tuv, ovf, counters);
+                       0, st, es, W, H, tan_half, rows, cnt, list, list_stride, hit, tuv, ovf, counters);
     return launched("resolve_primary");
 }
 

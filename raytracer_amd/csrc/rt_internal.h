@@ -289,6 +289,7 @@ struct SweepArgs {
     // grid is sized for; total_rays their sum).
     int lights;
     long light_ray_stride, light_plane_stride;
+    long list_stride;       // pixel-grid sweep: entry c of pixel p is list[c * list_stride + p] (neighbouring pixels' entries side by side)
     const int* live_counts;
     long total_rays;
     long est_rays;          // the host's estimate of the rays really alive (<= total_rays; 0: unknown):
@@ -446,7 +447,7 @@ struct ExactScene {
     const double* tv;
 };
 int rt_launch_resolve_primary(const ExactScene& es, int W, int H, double tan_half, const RowMap& rows,
-                              const int32_t* cnt, const int32_t* list,
+                              const int32_t* cnt, const int32_t* list, long list_stride,
                               int32_t* hit, double* tuv, int32_t* ovf, int* counters,
                               hipStream_t st);
 // gate (or nullptr): ray p is skipped altogether (no output written) when gate[p % gate_n] < 0:

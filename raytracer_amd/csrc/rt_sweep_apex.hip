@@ -103,7 +103,9 @@ __device__ __forceinline__ Tri2 load_tri2(const float4* p) { return {p[0], p[RT_
 __device__ __forceinline__ void push_mem(const SweepArgs& A, long slot, int tri)
 {
     const int c = atomicAdd(&A.cnt[slot], 1);
-    if (c < RT_RASTER_LIST_K) A.list[slot * RT_RASTER_LIST_K + c] = tri;
+    // (slot-major: the pixels of a box are neighbours and list the triangle at the same time, so
+    // their entries share cache lines -- pixel-major, every entry dirtied a sector of its own)
+    if (c < RT_RASTER_LIST_K) A.list[c * A.list_stride + slot] = tri;
 }
 
 // The inside test for one pixel that lies in the bounding box of triangle `tri` (candidate() of
