@@ -221,7 +221,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts,
                       &sc->scratch_max, &sc->mat_dev, &sc->ws_partials, &sc->ws_frame, &sc->planes_light, &sc->ws_sort_tri, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
-                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort, &sc->tri_order,
+                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort, &sc->tri_order, &sc->tri_scatter,
                       &sc->ws_cell_rays, &sc->ws_cell_table, &sc->ws_cell_boxes, &sc->ws_cell_wide};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : sc->tex_data) b.release();
@@ -342,6 +342,7 @@ extern "C" int rt_scene_set_triangles(rt_scene* sc, int num_tris, const int* A, 
     RT_TRY(sc->planes_apex.reserve(pb * (RT_APEX_PLANES + 1)));     // + the pixel-grid bounding boxes
     RT_TRY(sc->tri_verts.reserve(sizeof(double) * 9 * (size_t)(num_tris > 0 ? num_tris : 1)));
     RT_TRY(sc->scratch_max.reserve(16));
+    sc->tri_scatter_ready = false;
     sc->transformed = false;
     return RT_OK;
 }
@@ -648,7 +649,7 @@ static int row_map(const rt_rows* r, int H, RowMap* out)
 }
 
 static int lights_fork(rt_scene* sc, int lights);
-static int lights_launch(rt_scene* sc, const rt_frame* f, int lights);
+static int lights_launch(rt_scene* sc, const rt_frame* f, int lights, long npix);
 
 // aside_frame (or nullptr): the frame whose first aside_lights lights are sorted and packed on the
 // scene's side stream beside the sweep (see lights_fork / lights_launch)
@@ -710,7 +711,7 @@ static int trace_primary_rows(rt_scene* sc, int W, int H, double tan_half, const
     RT_TRY(timed_sweep([&] { return rt_launch_sweep_raster(a, st); }, false, tests, nullptr));
     // (queued by the host after the sweep, so that the sweep is not kept waiting for a dozen small
     // launches; on the device the side stream only waits for what preceded the sweep)
-    if (aside_frame) RT_TRY(lights_launch(sc, aside_frame, aside_lights));
+    if (aside_frame) RT_TRY(lights_launch(sc, aside_frame, aside_lights, (long)npix));
     if (g.profiling) g.prof.rays_primary += npix;
 #ifdef RT_RASTER_CHECK_INTERVAL
     {
@@ -1036,31 +1037,50 @@ static int trace_rays_impl(rt_scene* sc, const RayWorkspace* static_ws, int n, c
     return resolve_rays(sc, ws, n, S, E, anyhit, hit, tuv, point, occ);
 }
 
-// Whether the triangles of a light are put in the order of the solid angle they subtend at it
-// before its shadow rays are swept (rt_sort.hip).  Occluded rays then meet an occluder early and
-// retire, and the triangles of one tile lie all over the light's sky instead of side by side as
-// a mesh file lists them (side by side they send the waves that sweep them to the same few rays).
-// Measured at 3840x2160 with the cell-lattice sweep: a 100 000-triangle torus 4.2 ms a frame
-// sorted and 9.6 ms not, a 69 000-triangle sphere 6.2 and 14.4 ms; a soup of a million triangles
-// in random order 13.3 and 13.0 ms.  RT_AMD_SORT_TRIS=0 leaves the sort out (read at every call).
-static bool sort_light_triangles()
+// The order in which a light's plane set holds the triangles (rt_scene::lights_order):
+//   1  by the solid angle they subtend at the light, largest first (rt_sort.hip), a sort per light
+//      and frame: occluded rays meet an occluder early, which the ray-by-ray sweep in triangle
+//      ranges gains from (rays that retire in the first ranges drop out of the later ones);
+//   2  one fixed pseudo-random order for all lights, computed once per mesh: the cell-lattice
+//      sweep meets every triangle in one launch and only needs the tiles it deals to its
+//      workgroups to be alike -- in a mesh file's own order the triangles of a tile lie side by
+//      side and send their workgroup to the same few rays.  Measured at 3840x2160 with the lattice
+//      sweep (frame, ms): 100 000-triangle torus 9.6 in file order, 4.2 by solid angle, 3.7
+//      scattered; 69 000-triangle sphere 14.4, 5.7, 4.8; a soup of a million triangles (random
+//      order as generated) 10.4, 10.7, 10.7 -- and an eighth of that frame spends no 0.8 ms on
+//      two sorts it does not need;
+//   0  as the mesh lists them.
+// Order 2 is taken when even the first, coarsest level of the shadow pass (one pixel in sixteen)
+// is large enough for the lattice sweep, order 1 otherwise.  RT_AMD_SORT_TRIS = 0 / 1 / 2 forces
+// one (read at every call).
+static int light_triangle_order(const rt_scene* sc, long npix, int lights)
 {
-    const char* e = getenv("RT_AMD_SORT_TRIS");
-    return !(e && atoi(e) == 0);
+    if (const char* e = getenv("RT_AMD_SORT_TRIS")) {
+        const int v = atoi(e);
+        return v < 0 || v > 2 ? 1 : v;
+    }
+    constexpr int coarsest = RT_SHADOW_STEPS[0] * RT_SHADOW_STEPS[0];
+    return use_cell_lattice(npix * lights / coarsest, sc->num_tris_padded) ? 2 : 1;
 }
 
 // Plane sets of lights [l0, l0 + lights) for one any-hit launch, on stream st: every light's
-// triangles in the order of the solid angle they subtend at it (unless sort_light_triangles says
-// otherwise), packed relative to the light.  |D'| <= sqrt(3) for a direction scaled to a unit
-// dominant component.
-static int prepare_lights(rt_scene* sc, const rt_frame* f, int l0, int lights, hipStream_t st)
+// triangles in the order light_triangle_order chooses, packed relative to the light.
+// |D'| <= sqrt(3) for a direction scaled to a unit dominant component.  npix: pixels of the
+// call (every one of them may send a ray to every light).
+static int prepare_lights(rt_scene* sc, const rt_frame* f, int l0, int lights, long npix, hipStream_t st)
 {
-    const bool sort_tris = sort_light_triangles();
-    sc->lights_sorted = sort_tris;
+    const int order = light_triangle_order(sc, npix, lights);
+    sc->lights_order = order;
+    if (order == 2 && !sc->tri_scatter_ready) {
+        RT_TRY(sc->tri_scatter.reserve(sizeof(int32_t) * (size_t)sc->num_tris_padded));
+        RT_TRY(rt_launch_scatter_triangles(sc, sc->tri_scatter.as<int32_t>(), st));
+        sc->tri_scatter_ready = true;
+    }
     const size_t set_planes = (size_t)RT_LIGHT_PLANES * sc->num_tris_padded;
     for (int k = 0; k < lights; ++k) {
-        int32_t* ord = sort_tris ? sc->tri_order.as<int32_t>() + (size_t)k * sc->num_tris_padded : nullptr;
-        if (ord) RT_TRY(rt_launch_sort_triangles(sc, f->light_in_eye_space[l0 + k], ord, st));
+        int32_t* ord = order == 1 ? sc->tri_order.as<int32_t>() + (size_t)k * sc->num_tris_padded
+                                  : (order == 2 ? sc->tri_scatter.as<int32_t>() : nullptr);
+        if (order == 1) RT_TRY(rt_launch_sort_triangles(sc, f->light_in_eye_space[l0 + k], ord, st));
         float4* dst = sc->planes_light.as<float4>() + k * set_planes;
         RT_TRY(rt_launch_pack_apex(sc, f->light_in_eye_space[l0 + k], 1.0, 1.75, dst, false, ord, st,
                                    dst + (size_t)RT_APEX_PLANES * sc->num_tris_padded));
@@ -1093,10 +1113,10 @@ static int lights_fork(rt_scene* sc, int lights)
     return RT_OK;
 }
 
-static int lights_launch(rt_scene* sc, const rt_frame* f, int lights)
+static int lights_launch(rt_scene* sc, const rt_frame* f, int lights, long npix)
 {
     RT_HIP(hipStreamWaitEvent(sc->side_stream, sc->ev_fork, 0));
-    const int rc = prepare_lights(sc, f, 0, lights, sc->side_stream);
+    const int rc = prepare_lights(sc, f, 0, lights, npix, sc->side_stream);
     RT_HIP(hipEventRecord(sc->ev_join, sc->side_stream));      // also after a failed launch: the join must not hang
     return rc;
 }
@@ -1127,12 +1147,14 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
             RT_HIP(hipStreamWaitEvent(st, sc->ev_join, 0));     // prepare_lights_aside
         } else {
             RT_TRY(reserve_light_buffers(sc, lights));
-            RT_TRY(prepare_lights(sc, f, l0, lights, st));
+            RT_TRY(prepare_lights(sc, f, l0, lights, (long)npix, st));
         }
-        int32_t* order = sc->lights_sorted ? sc->tri_order.as<int32_t>() : nullptr;
+        int32_t* order = sc->lights_order == 1 ? sc->tri_order.as<int32_t>()
+                                               : (sc->lights_order == 2 ? sc->tri_scatter.as<int32_t>() : nullptr);
         SweepArgs a{};
         a.cull = rt_tile_culling() ? 1 : 0;
         a.tri_order = order;
+        a.tri_order_stride = sc->lights_order == 1 ? sc->num_tris_padded : 0;
         a.planes = sc->planes_light.as<float4>(); a.plane_stride = sc->num_tris_padded;
         a.light_plane_stride = (long)RT_LIGHT_PLANES * sc->num_tris_padded;
         a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;

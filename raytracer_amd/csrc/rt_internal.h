@@ -150,7 +150,11 @@ struct rt_scene {
     DevBuf planes;
     // same for the apex sweeps: RT_APEX_PLANES planes, repacked for the eye and for each light
     DevBuf planes_apex, tri_order;
-    bool lights_sorted = false;     // whether the current lights' planes are in tri_order's order (else: triangle order)
+    // Order of the current lights' plane sets: 0 = triangle order, 1 = tri_order (a list per light, by
+    // the solid angle subtended at it), 2 = tri_scatter (one fixed pseudo-random list for every light)
+    int lights_order = 0;
+    DevBuf tri_scatter;
+    bool tri_scatter_ready = false; // computed for the current triangle count
     // ... and for the lights of one any-hit launch (RT_APEX_LIGHTS sets side by side), sorted and
     // packed on a side stream while the primary sweep runs
     DevBuf planes_light, ws_sort_tri;
@@ -295,8 +299,10 @@ struct SweepArgs {
     long est_rays;          // the host's estimate of the rays really alive (<= total_rays; 0: unknown):
                             // picks rays per lane and triangle chunks, never an array bound
     int32_t* occ_id;        // per ray (laid out like cnt): the triangle of its certain hit, or nullptr
-    // entry k of light l's planes holds triangle tri_order[l * num_tris_padded + k] (nullptr: k)
+    // entry k of light l's planes holds triangle tri_order[l * tri_order_stride + k] (nullptr: k;
+    // the stride is num_tris_padded, or 0 when all lights share one list)
     const int32_t* tri_order;
+    long tri_order_stride;
     // pixel-grid sweep only: the triangle range is cut into `chunks` equal parts that run as
     // separate workgroups; the chunks of a pixel share its count, list and bound
     int chunks;
@@ -368,6 +374,7 @@ constexpr int RT_SHADOW_STEPS[RT_SHADOW_LEVELS] = {4, 1};
 // (s / cnt_div) * stride rays in): set s takes its n from in_counts[s] when `in` is given, else
 // all n rays; writes out_counts[s]
 int rt_launch_sort_triangles(rt_scene* sc, const double apex[3], int32_t* order, hipStream_t st);
+int rt_launch_scatter_triangles(rt_scene* sc, int32_t* order, hipStream_t st);
 int rt_launch_sort_rays(rt_scene* sc, const double* S, const double* E, const int32_t* ids_in,
                         int32_t* ids_out, const int* counts, const int* counts_dev, int sets,
                         long stride, hipStream_t st);
@@ -408,7 +415,8 @@ struct CellArgs {
     const float2* len_sig;  // same order: |light - S| and 1 / (unit direction)_k, for the rare path's ray parameter
     const int32_t* slot;    // the ray's entry in cnt / list / occ_id
     int32_t *cnt, *list, *occ_id;
-    const int32_t* tri_order;   // entry k of light l's planes holds triangle tri_order[l * num_tris_padded + k] (nullptr: k)
+    const int32_t* tri_order;   // entry k of light l's planes holds triangle tri_order[l * tri_order_stride + k] (nullptr: k)
+    long tri_order_stride;      // num_tris_padded, or 0 when all lights share one list
     unsigned long long* ray_pairs;  // (ray, triangle) pairs tested one by one, accumulated (may be nullptr);
                                     // [2]: cell-table look-ups, [3]: rare-path entries of waves
     int debug_skip;                 // measurement only: leave the rare path out (wrong results)

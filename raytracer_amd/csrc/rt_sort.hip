@@ -120,6 +120,21 @@ k_tri_keys(const double* __restrict__ x, const double* __restrict__ y, const dou
     ids[i] = i < num_tris ? i : -1;
 }
 
+// Keys of a fixed pseudo-random order of the triangles (a hash of the triangle number; the
+// padding sorts last).
+__global__ void __launch_bounds__(RT_WG)
+k_scatter_keys(int num_tris, int num_tris_padded, unsigned* __restrict__ keys, int32_t* __restrict__ ids)
+{
+    const int i = blockIdx.x * RT_WG + threadIdx.x;
+    if (i >= num_tris_padded) return;
+    unsigned h = (unsigned)i * 2654435761u;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    keys[i] = i < num_tris ? h >> 1 : 0xFFFFFFFFu;
+    ids[i] = i < num_tris ? i : -1;
+}
+
 }  // namespace
 
 // Order in which the any-hit sweep of the rays through `apex` visits the triangles: by the solid
@@ -145,6 +160,35 @@ int rt_launch_sort_triangles(rt_scene* sc, const double apex[3], int32_t* order,
     hipLaunchKernelGGL(k_tri_keys, dim3((np + RT_WG - 1) / RT_WG), dim3(RT_WG), 0, st, sc->ex.as<double>(),
                        sc->ey.as<double>(), sc->ez.as<double>(), sc->iA.as<int>(), sc->iB.as<int>(),
                        sc->iC.as<int>(), sc->num_tris, (int)np, apex[0], apex[1], apex[2], keys_in, ids_in);
+    RT_HIP(hipGetLastError());
+    RT_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, ids_in, order, np, 0u, 32u, st));
+    return RT_OK;
+}
+
+// A fixed order that scatters the triangles: neighbours in the mesh file (neighbours in space,
+// for a tessellated surface) land in different tiles.  The cell-lattice sweep deals the tiles to
+// its workgroups, and a tile whose triangles lie side by side sends its workgroup to the same few
+// rays again and again while others idle; scattered, every tile is a sample of the whole mesh.
+// Computed once per mesh (it does not depend on the apex).  order[k] = triangle at position k,
+// -1 for the padding at the end.
+int rt_launch_scatter_triangles(rt_scene* sc, int32_t* order, hipStream_t st)
+{
+    const unsigned np = (unsigned)sc->num_tris_padded;
+    if (np == 0) return RT_OK;
+    size_t temp_bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, temp_bytes, (unsigned*)nullptr, (unsigned*)nullptr,
+                                  (int32_t*)nullptr, (int32_t*)nullptr, np, 0u, 32u, st) != hipSuccess) {
+        rt_set_error("triangle scatter: size query failed");
+        return RT_E_HIP;
+    }
+    const size_t arr = ((size_t)np * 4 + 255) & ~(size_t)255;
+    if (int rc = sc->ws_sort_tri.reserve(3 * arr + temp_bytes)) return rc;
+    unsigned* keys_in = sc->ws_sort_tri.as<unsigned>();
+    unsigned* keys_out = reinterpret_cast<unsigned*>(sc->ws_sort_tri.as<char>() + arr);
+    int32_t* ids_in = reinterpret_cast<int32_t*>(sc->ws_sort_tri.as<char>() + 2 * arr);
+    void* temp = sc->ws_sort_tri.as<char>() + 3 * arr;
+    hipLaunchKernelGGL(k_scatter_keys, dim3((np + RT_WG - 1) / RT_WG), dim3(RT_WG), 0, st, sc->num_tris, (int)np,
+                       keys_in, ids_in);
     RT_HIP(hipGetLastError());
     RT_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, ids_in, order, np, 0u, 32u, st));
     return RT_OK;

@@ -934,7 +934,7 @@ k_sweep_apex(SweepArgs A)
     A.cnt += light * A.light_ray_stride;
     A.list += light * A.light_ray_stride * RT_LIST_K;
     if (A.occ_id) A.occ_id += light * A.light_ray_stride;
-    if (A.tri_order) A.tri_order += light * A.num_tris_padded;
+    if (A.tri_order) A.tri_order += light * A.tri_order_stride;
     A.active += set * A.light_ray_stride;
     A.n_rays = A.live_counts[set];
     if ((long)blockIdx.x * (RT_WG * R) >= A.n_rays) return;     // the grid is sized for the largest set

@@ -314,7 +314,7 @@ k_sweep_cells(const CellArgs A)
     X.gu_log2 = cs.gu_log2;
     X.cell_base = cs.cell_base;
     X.fine_log2 = A.fine_log2;
-    X.tri_order = A.tri_order ? A.tri_order + (long)cs.light * A.num_tris_padded : nullptr;
+    X.tri_order = A.tri_order ? A.tri_order + (long)cs.light * A.tri_order_stride : nullptr;
 
     const int f = (int)blockIdx.x - cs.fp_base;
     const int fx = f & ((1 << cs.fp_cols_log2) - 1), fy = f >> cs.fp_cols_log2;
@@ -528,7 +528,7 @@ k_cells_wide(const CellArgs A, const int* __restrict__ wide)
     X.gu_log2 = cs.gu_log2;
     X.cell_base = cs.cell_base;
     X.fine_log2 = A.fine_log2;
-    X.tri_order = A.tri_order ? A.tri_order + (long)cs.light * A.num_tris_padded : nullptr;
+    X.tri_order = A.tri_order ? A.tri_order + (long)cs.light * A.tri_order_stride : nullptr;
     const int ax = cs.axis;
     const float qnan = __builtin_nanf("");
     unsigned tested = 0;
@@ -766,6 +766,7 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     A.list = a.list;
     A.occ_id = a.occ_id;
     A.tri_order = a.tri_order;
+    A.tri_order_stride = a.tri_order_stride;
     A.ray_pairs = nullptr;
     plan->wide = sc->ws_cell_wide.as<int>();
     plan->largest_set = largest;

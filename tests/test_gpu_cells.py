@@ -75,12 +75,12 @@ def test_lattice_frames_equal_ray_by_ray_frames(kind, tris, W, H, frame_no, monk
 
 @pytest.mark.parametrize("shape", ["2048", "2048,7", "512,3", "128,1", "128,40", "32,2", "8,1", "8,5"])
 @pytest.mark.parametrize("cells_per_ray", ["0.02", "0.5", "16"])
-@pytest.mark.parametrize("fine,sort", [("0.001", None), ("1", "1"), ("4096", None)])
+@pytest.mark.parametrize("fine,sort", [("0.001", None), ("1", "1"), ("4096", None), ("1", "0")])
 def test_every_shape_of_the_cell_sweep(shape, cells_per_ray, fine, sort, monkeypatch):
     """Every kernel shape (cells per lane, triangle chunks) on coarse and fine grids, with the
     rays looked up by the lattice's own cells (fine = 0.001 per ray), by 4 or 16 fine cells per
-    cell, or by as many as the launch allows (256 per cell), and with the triangles in the order
-    of their solid angle or as they come: equal to the ray-by-ray sweep, which equals the oracle
+    cell, or by as many as the launch allows (256 per cell), and with the triangles in the lattice's fixed scattered
+    order (the default there), in the order of their solid angle, or as the mesh lists them: equal to the ray-by-ray sweep, which equals the oracle
     in the other files."""
     mesh = scenes.with_materials(scenes.triangle_soup(2500, seed=5))
     fr = kernel.driver_frame(7)
