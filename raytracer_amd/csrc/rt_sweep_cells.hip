@@ -28,7 +28,7 @@
 // triangle's planes are fetched from memory by the few waves that need them.
 #include "rt_sweep_common.h"
 
-#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #ifndef RT_CELLS_WAVES
 #define RT_CELLS_WAVES 8    // waves per SIMD the kernel must fit (64 registers)
@@ -394,11 +394,13 @@ struct CellKeySets {
 };
 
 // blockIdx.y = set.  Ray i of the set: its (u, v) and (len, sig) exactly as k_sweep_apex forms
-// it, its slot, and the number of its cell as the sort key.
+// it, its slot, and the number of its fine cell, counted in hist.  The rays are then put in the
+// order of their fine cells by a counting sort: a running sum over hist gives the table (rays
+// in the cells before each one), and k_cell_place hands every ray a place among its cell's.
 __global__ void __launch_bounds__(RT_WG)
 k_cell_keys(const double* __restrict__ S, const double* __restrict__ E, const int32_t* __restrict__ lists,
             long stride, const int32_t* __restrict__ cnt, CellKeySets ks, unsigned* __restrict__ keys,
-            int32_t* __restrict__ vals, float2* __restrict__ rec, float2* __restrict__ len_sig,
+            int* __restrict__ hist, float2* __restrict__ rec, float2* __restrict__ len_sig,
             int32_t* __restrict__ slot)
 {
     const CellSet cs = ks.set[blockIdx.y];
@@ -431,42 +433,30 @@ k_cell_keys(const double* __restrict__ S, const double* __restrict__ E, const in
         col = col < 0 ? 0 : (col > gu - 1 ? gu - 1 : col);
         row = row < 0 ? 0 : (row > gv - 1 ? gv - 1 : row);
         const long g = cs.ray_base + i;
-        keys[g] = key_base + (unsigned)((row << (cs.gu_log2 + fl)) + col);
-        vals[g] = (int32_t)g;
+        const unsigned key = key_base + (unsigned)((row << (cs.gu_log2 + fl)) + col);
+        keys[g] = key;
+        atomicAdd(&hist[key], 1);               // rays per fine cell
         rec[g] = make_float2(valid ? u : qnan, v);
         len_sig[g] = make_float2((float)len, (float)sig);
         slot[g] = (int32_t)sl;
     }
 }
 
-// The records into cell order.
+// The records into cell order: a ray's place is its cell's first (table) plus what is left of
+// the cell's count when the ray takes one off (the order of a cell's rays among themselves is
+// whatever the atomics make it; no result depends on it).
 __global__ void __launch_bounds__(RT_WG)
-k_cell_gather(const int32_t* __restrict__ vals, int n, const float2* __restrict__ rec_in,
-              const float2* __restrict__ ls_in, const int32_t* __restrict__ slot_in, float2* __restrict__ rec,
-              float2* __restrict__ ls, int32_t* __restrict__ slot)
+k_cell_place(const unsigned* __restrict__ keys, int n, const int* __restrict__ table, int* __restrict__ hist,
+             const float2* __restrict__ rec_in, const float2* __restrict__ ls_in, const int32_t* __restrict__ slot_in,
+             float2* __restrict__ rec, float2* __restrict__ ls, int32_t* __restrict__ slot)
 {
     const int j = blockIdx.x * RT_WG + threadIdx.x;
     if (j >= n) return;
-    const int src = vals[j];
-    rec[j] = rec_in[src];
-    ls[j] = ls_in[src];
-    slot[j] = slot_in[src];
-}
-
-// The cell table: table[c] = number of rays in the cells before c (a search in the sorted keys),
-// for c = 0 .. cells: the rays of the cells a .. b-1 are rays[table[a] .. table[b]).
-__global__ void __launch_bounds__(RT_WG)
-k_cell_table(const unsigned* __restrict__ keys, int n, int cells, int* __restrict__ table)
-{
-    const int c = blockIdx.x * RT_WG + threadIdx.x;
-    if (c > cells) return;
-    int lo = 0, hi = n;                 // first j with keys[j] >= c
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (keys[mid] < (unsigned)c) lo = mid + 1;
-        else hi = mid;
-    }
-    table[c] = lo;
+    const unsigned key = keys[j];
+    const int at = table[key] + atomicSub(&hist[key], 1) - 1;
+    rec[at] = rec_in[j];
+    ls[at] = ls_in[j];
+    slot[at] = slot_in[j];
 }
 
 // blockIdx.y = set.  The set's squares (cu, cv, rho) on [-1, 1]^2 in units of its cells: cell c
@@ -696,33 +686,34 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
         plan->chunks = c < 1 ? 1 : (int)c;
     }
 
-    // workspace: sort keys and values (in, out), records and slots (by ray, by cell), rocPRIM's own
-    unsigned key_bits = 1;
-    while ((1L << key_bits) < fine_cells) ++key_bits;
+    // workspace: keys, records and slots (by ray, by cell); the table, the per-cell counts and
+    // rocPRIM's own for the running sum
     size_t temp_bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, temp_bytes, (unsigned*)nullptr, (unsigned*)nullptr, (int32_t*)nullptr,
-                                  (int32_t*)nullptr, (unsigned)n, 0u, key_bits, st) != hipSuccess) {
-        rt_set_error("cell sweep: sort size query failed");
+    if (rocprim::exclusive_scan(nullptr, temp_bytes, (int*)nullptr, (int*)nullptr, 0, (size_t)fine_cells + 1,
+                                rocprim::plus<int>(), st) != hipSuccess) {
+        rt_set_error("cell sweep: scan size query failed");
         return RT_E_HIP;
     }
+    temp_bytes = (temp_bytes + 255) & ~(size_t)255;
     const size_t a4 = ((size_t)n * 4 + 255) & ~(size_t)255, a8 = ((size_t)n * 8 + 255) & ~(size_t)255;
-    RT_TRY(sc->ws_cell_rays.reserve(6 * a4 + 4 * a8 + temp_bytes));
-    RT_TRY(sc->ws_cell_table.reserve(sizeof(int) * ((size_t)fine_cells + 1)));
+    const size_t t4 = (((size_t)fine_cells + 1) * 4 + 255) & ~(size_t)255;
+    RT_TRY(sc->ws_cell_rays.reserve(3 * a4 + 4 * a8));
+    RT_TRY(sc->ws_cell_table.reserve(2 * t4 + temp_bytes));
     RT_TRY(sc->ws_cell_boxes.reserve(sizeof(float4) * (size_t)np * plan->args.sets));
     RT_TRY(sc->ws_cell_wide.reserve(sizeof(int) * (RT_CELLS_WIDE_CAP + 1) * RT_APEX_SETS));
     RT_HIP(hipMemsetAsync(sc->ws_cell_wide.p, 0, sizeof(int) * (RT_CELLS_WIDE_CAP + 1) * RT_APEX_SETS, st));
     char* ws = sc->ws_cell_rays.as<char>();
-    unsigned* keys_in = reinterpret_cast<unsigned*>(ws);
-    unsigned* keys_out = reinterpret_cast<unsigned*>(ws + a4);
-    int32_t* vals_in = reinterpret_cast<int32_t*>(ws + 2 * a4);
-    int32_t* vals_out = reinterpret_cast<int32_t*>(ws + 3 * a4);
-    int32_t* slot_in = reinterpret_cast<int32_t*>(ws + 4 * a4);
-    int32_t* slot = reinterpret_cast<int32_t*>(ws + 5 * a4);
-    float2* rec_in = reinterpret_cast<float2*>(ws + 6 * a4);
-    float2* rec = reinterpret_cast<float2*>(ws + 6 * a4 + a8);
-    float2* ls_in = reinterpret_cast<float2*>(ws + 6 * a4 + 2 * a8);
-    float2* ls = reinterpret_cast<float2*>(ws + 6 * a4 + 3 * a8);
-    void* temp = ws + 6 * a4 + 4 * a8;
+    unsigned* keys = reinterpret_cast<unsigned*>(ws);
+    int32_t* slot_in = reinterpret_cast<int32_t*>(ws + a4);
+    int32_t* slot = reinterpret_cast<int32_t*>(ws + 2 * a4);
+    float2* rec_in = reinterpret_cast<float2*>(ws + 3 * a4);
+    float2* rec = reinterpret_cast<float2*>(ws + 3 * a4 + a8);
+    float2* ls_in = reinterpret_cast<float2*>(ws + 3 * a4 + 2 * a8);
+    float2* ls = reinterpret_cast<float2*>(ws + 3 * a4 + 3 * a8);
+    int* table = sc->ws_cell_table.as<int>();
+    int* hist = reinterpret_cast<int*>(sc->ws_cell_table.as<char>() + t4);
+    void* temp = sc->ws_cell_table.as<char>() + 2 * t4;
+    RT_HIP(hipMemsetAsync(hist, 0, t4, st));
 
     CellKeySets ks{};
     ks.sets = plan->args.sets;
@@ -735,15 +726,12 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     unsigned wgs = (unsigned)((largest + RT_WG - 1) / RT_WG);
     if (wgs > 4096) wgs = 4096;
     hipLaunchKernelGGL(k_cell_keys, dim3(wgs, ks.sets), dim3(RT_WG), 0, st, a.S, a.E, lists, a.light_ray_stride,
-                       a.cnt, ks, keys_in, vals_in, rec_in, ls_in, slot_in);
+                       a.cnt, ks, keys, hist, rec_in, ls_in, slot_in);
     RT_HIP(hipGetLastError());
-    RT_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (unsigned)n, 0u,
-                                     key_bits, st));
-    hipLaunchKernelGGL(k_cell_gather, dim3((unsigned)((n + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0, st, vals_out, n,
+    // table[c] = rays in the fine cells before c, for c = 0 .. fine_cells (the last entry: all of them)
+    RT_HIP(rocprim::exclusive_scan(temp, temp_bytes, hist, table, 0, (size_t)fine_cells + 1, rocprim::plus<int>(), st));
+    hipLaunchKernelGGL(k_cell_place, dim3((unsigned)((n + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0, st, keys, n, table, hist,
                        rec_in, ls_in, slot_in, rec, ls, slot);
-    RT_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_cell_table, dim3((unsigned)((fine_cells + 1 + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0, st,
-                       keys_out, n, (int)fine_cells, sc->ws_cell_table.as<int>());
     RT_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_cell_boxes, dim3((unsigned)((np + RT_WG - 1) / RT_WG), ks.sets), dim3(RT_WG), 0, st, a.planes,
                        a.plane_stride, a.light_plane_stride, np, ks, wide_cells, sc->ws_cell_boxes.as<float4>(),
@@ -758,7 +746,7 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     A.num_tris_padded = np;
     A.tri_begin = 0;
     A.tri_end = np;
-    A.table = sc->ws_cell_table.as<int>();
+    A.table = table;
     A.rays = rec;
     A.len_sig = ls;
     A.slot = slot;
