@@ -359,6 +359,21 @@ def main() -> None:
     _lib.load().rt_raster_sweep_mix(*[C.byref(m) for m in mix])
     regular = C.c_int()
     _lib.load().rt_raster_sweep_form(C.byref(regular))
+    # The primary launch once more with its rare path left out (RT_AMD_RASTER_SKIP_RARE, a measurement
+    # switch the library reads at every call; the hits of that launch are wrong and are thrown away):
+    # what the hot loop alone takes, i.e. how much of the launch is the instruction-bound part.
+    hot_only_ms = None
+    if world == 1 and not single and not sequence:
+        os.environ["RT_AMD_RASTER_SKIP_RARE"] = "1"
+        try:
+            kernel.profile_enable(True)
+            kernel.profile_reset()
+            sc.trace_primary(W, H, TAN_HALF)
+            p2 = kernel.profile_get()
+            hot_only_ms = p2.sweep_ms / max(p2.sweep_launches, 1)
+        finally:
+            kernel.profile_enable(False)
+            del os.environ["RT_AMD_RASTER_SKIP_RARE"]
 
     # The same steps once more with the library's tile culling on (off by default: the headline
     # is the all-pairs sweep).  Every wave still visits every triangle, but tests a tile's
@@ -412,7 +427,9 @@ def main() -> None:
         achieved = tests_per_s_launch * f_exec / 1e12
         traffic = measured_traffic(args.workload, f"raster-tile{tile.value}-ppl{ppl.value}-chunks{chunks.value}") if world == 1 else None
         ms_step = wall / steps * 1e3
-        raster_name = f"k_sweep_raster<{ppl.value}, false, {'true' if regular.value else 'false'}>"
+        # (4096 pixels per lane and more: the wave-block form, 4096 columns by 64 NL rows per workgroup)
+        raster_name = (f"k_sweep_raster_wave<{ppl.value // 4096}>" if ppl.value >= 4096 else
+                       f"k_sweep_raster<{ppl.value}, false, {'true' if regular.value else 'false'}>")
         rp = rocprof_avg_ms(args.workload, raster_name) if world == 1 else None
         # the any-hit sweeps of the shadow rays
         sh_ms, sh_tests = prof.shadow_ms, float(prof.shadow_tests)
@@ -533,16 +550,24 @@ def main() -> None:
             # ray-triangle pair (an addition = 1; rocprof SQ_INSTS_VALU_{ADD,MUL,FMA}_F32 agree,
             # see profiles/) against the fp32 vector peak.  What actually bounds the loop is
             # instruction issue (one VALU instruction per SIMD every two cycles, whatever it
-            # computes): a lane's pixels are a lattice of rows and columns, and per triangle it
+            # computes): the pixels of a lane (lattice form) or of a wave's block (wave-block form,
+            # 4096 pixels per lane and more) are rows times columns, and per triangle the loop
             # steps each column's and each row's distance from the centre of the triangle's
             # bounding box by one addition or subtraction and collects two of those in a three-way
             # minimum (a pixel is in the box when its column and its row are), so `valu_issue` is
-            # the figure that says how close the kernel is to the machine's limit, and the stated
-            # target of half the fp32 flop peak is not met by construction.  The pairs are those
-            # of the image's own pixels: the lanes of a wave that reaches beyond the right edge
-            # execute their tests too, uncounted.
+            # the figure that says how close the hot loop is to the machine's limit, and the stated
+            # target of half the fp32 flop peak is not met by construction.  With the tall blocks
+            # of the wave-block form that loop is a small part of the launch (`hot_loop_only_ms`);
+            # the rest is the rare path, which works through the pixel rectangles of the triangles
+            # that passed, bound by memory latency, not by arithmetic (`bound` says which it is).
+            # The pairs are those of the image's own pixels: columns beyond the right edge and
+            # rows beyond the bottom are tested too, uncounted.
             "roofline": {
-                "bound": "valu-fp32", "kernel": f"{raster_name} (primary rays, closest hit, all pairs)",
+                "bound": "valu-fp32" if hot_only_ms is None or hot_only_ms >= 0.5 * sweep_ms_avg else
+                         "latency of the rare path (the hot loop alone: hot_loop_only_ms; the figures below are the hot loop's)",
+                "hot_loop_only_ms": hot_only_ms,
+                "hot_loop_share_of_launch": (hot_only_ms / sweep_ms_avg) if hot_only_ms and sweep_ms_avg > 0 else None,
+                "kernel": f"{raster_name} (primary rays, closest hit, all pairs)",
                 "dominant_by_time": "this kernel" if primary_ms >= sh_ms else "anyhit (below)",
                 "share_of_step": primary_ms / ms_step,
                 "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
@@ -562,7 +587,7 @@ def main() -> None:
                                "frac": tests_per_s_launch * instr_per_test / 1e12 / PEAK_VALU_TINSTR,
                                # the same instruction sequence with nothing around it (no LDS reads,
                                # barriers, branches or rare path), measured by tools/microbench/valu_rate
-                               **mix_alone(f"raster{mix_ppl}_box", tests_per_s_launch)},
+                               **mix_alone(f"raster{mix_ppl}_wave" if mix_ppl >= 4096 else f"raster{mix_ppl}_box", tests_per_s_launch)},
                 "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
                 "sweep_kernel": {"tile_tris": tile.value, "pixels_per_lane": ppl.value,

@@ -219,7 +219,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
     DevBuf* bufs[] = {&sc->ox, &sc->oy, &sc->oz, &sc->ex, &sc->ey, &sc->ez, &sc->nx, &sc->ny, &sc->nz,
                       &sc->tu, &sc->tv, &sc->iA, &sc->iB, &sc->iC, &sc->iAn, &sc->iBn, &sc->iCn,
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts,
-                      &sc->scratch_max, &sc->mat_dev, &sc->ws_partials, &sc->ws_frame, &sc->planes_light, &sc->ws_sort_tri, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi,
+                      &sc->scratch_max, &sc->mat_dev, &sc->ws_partials, &sc->ws_frame, &sc->planes_light, &sc->ws_sort_tri, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi, &sc->ws_axis,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
                       &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort, &sc->tri_order, &sc->tri_scatter,
                       &sc->ws_cell_rays, &sc->ws_cell_table, &sc->ws_cell_boxes, &sc->ws_cell_wide};
@@ -1125,7 +1125,7 @@ static int lights_launch(rt_scene* sc, const rt_frame* f, int lights, long npix)
 // Apex sweeps over planes packed relative to each light (rt_sweep_apex.hip), RT_APEX_LIGHTS
 // lights per launch; the rays of a light are binned by the dominant axis of their direction.
 static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, int row_block,
-                             const double* S, const double* E, const int32_t* hit, uint8_t* occ,
+                             const double* S, const double* E, const int8_t* axis, const int32_t* hit, uint8_t* occ,
                              bool first_group_aside)
 {
     hipStream_t st = rt_g().stream;
@@ -1159,6 +1159,7 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
         a.light_plane_stride = (long)RT_LIGHT_PLANES * sc->num_tris_padded;
         a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;
         a.S = S + 3 * npix * (size_t)l0; a.E = E + 3 * npix * (size_t)l0;
+        const int8_t* ax = axis ? axis + npix * (size_t)l0 : nullptr;   // the rays' dominant axes, written with them
         a.cnt = sc->ws_cnt.as<int32_t>() + npix * (size_t)l0;
         a.list = sc->ws_list.as<int32_t>() + npix * (size_t)l0 * RT_LIST_K;
         a.tests = reinterpret_cast<unsigned long long*>(sc->ws_counters.as<char>() + 8);
@@ -1177,7 +1178,7 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
         };
         RT_HIP(hipMemsetAsync(sc->ws_live.p, 0, sizeof(int) * 3 * RT_APEX_SETS, st));
         if (!use_cache) {
-            RT_TRY(rt_launch_bin_rays(a.S, a.E, hit, W, nrows, lights, (long)npix, 1, 0, act0, live0, st));
+            RT_TRY(rt_launch_bin_rays(a.S, a.E, ax, hit, W, nrows, lights, (long)npix, 1, 0, act0, live0, st));
             RT_TRY(phase());
             continue;
         }
@@ -1194,10 +1195,10 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
             a.occ_id = record ? occ_id : nullptr;
             RT_HIP(hipMemsetAsync(live0, 0, sizeof(int) * 3 * RT_APEX_SETS, st));
             if (level == 0) {
-                RT_TRY(rt_launch_bin_rays(a.S, a.E, hit, W, nrows, lights, (long)npix, step, 0, act0, live0, st));
+                RT_TRY(rt_launch_bin_rays(a.S, a.E, ax, hit, W, nrows, lights, (long)npix, step, 0, act0, live0, st));
             } else {
                 const int coarser = RT_SHADOW_STEPS[level - 1];
-                RT_TRY(rt_launch_bin_rays(a.S, a.E, hit, W, nrows, lights, (long)npix, step, coarser, act2, live2, st));
+                RT_TRY(rt_launch_bin_rays(a.S, a.E, ax, hit, W, nrows, lights, (long)npix, step, coarser, act2, live2, st));
                 RT_TRY(rt_launch_try_cached(exact_of(sc), a.S, a.E, act2, live2, sets, (int)npix, (long)npix,
                                             W, nrows, row_block, coarser, record, a.cnt, occ_id, st));
                 RT_TRY(rt_launch_compact(a.cnt, act2, live2, (int)npix, sets, (long)npix, 3, act0, live0,
@@ -1335,10 +1336,12 @@ static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, doubl
         RT_TRY(sc->ws_shS.reserve(sizeof(double) * 3 * nsh));
         RT_TRY(sc->ws_shE.reserve(sizeof(double) * 3 * nsh));
         RT_TRY(sc->ws_occ.reserve(nsh));
+        RT_TRY(sc->ws_axis.reserve(nsh));
         a.shS = sc->ws_shS.as<double>(); a.shE = sc->ws_shE.as<double>();
+        a.sh_axis = sc->ws_axis.as<int8_t>();
         a.occ = sc->ws_occ.as<uint8_t>();
         RT_TRY(rt_launch_shadow_setup(a, st));
-        RT_TRY(trace_shadow_rays(sc, f, W, rows.rows, rows.parts > 1 ? rows.block : rows.rows, a.shS, a.shE,
+        RT_TRY(trace_shadow_rays(sc, f, W, rows.rows, rows.parts > 1 ? rows.block : rows.rows, a.shS, a.shE, a.sh_axis,
                                  hit, sc->ws_occ.as<uint8_t>(), aside));
     }
     RT_TRY(rt_launch_shade_final(a, st));

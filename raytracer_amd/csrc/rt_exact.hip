@@ -397,21 +397,23 @@ k_try_cached(ExactScene es, const double* __restrict__ Sa, const double* __restr
         int wy = sy - LO * step;
         if (wy + (NB - 1) * step > last) wy = last - (NB - 1) * step;
         if (wy < first) wy = first;
+        // the recorded triangles around the ray first, all loads in flight together (tried one after
+        // the other, each look-up waited for the previous test: up to NB2 memory round trips in a row)
         int tried[NB2];
-#pragma unroll
-        for (int k = 0; k < NB2; ++k) tried[k] = -1;
 #pragma unroll
         for (int k = 0; k < NB2; ++k) {
             const int kx = k % NB, ky = k / NB;
             const int qx = sx + (kx - LO) * step, qy = wy + ky * step;
-            if (qx < 0 || qx >= W || qy > last) continue;
-            const int t = occ_id[(long)qy * W + qx];
+            tried[k] = (qx < 0 || qx >= W || qy > last) ? -1 : occ_id[(long)qy * W + qx];
+        }
+#pragma unroll
+        for (int k = 0; k < NB2; ++k) {
+            const int t = tried[k];
             if (t < 0 || t >= es.num_tris) continue;
             bool seen = false;
 #pragma unroll
             for (int m = 0; m < NB2; ++m) seen = seen || (m < k && tried[m] == t);
             if (seen) continue;
-            tried[k] = t;
             double u, v;
             if (exact_tri(es, t, S, E, u, v) > 0) {        // triangle_intersection.cu:169
                 atomicOr(&cnt[id], RT_CNT_OCCLUDED);

@@ -77,13 +77,20 @@ constexpr int RT_APEX_PLANES = 4;
 constexpr int RT_LIGHT_PLANES = RT_APEX_PLANES + 3;
 constexpr int RT_APEX_LIGHTS = 4;   // lights swept per any-hit launch (plane sets kept side by side)
 constexpr int RT_APEX_SETS = 3 * RT_APEX_LIGHTS;    // ray sets per launch: light x dominant axis
-// A lane's rpl pixels in the pixel-grid sweep are a block of this many rows (by rpl / rows columns).
-constexpr int rt_raster_lane_rows(int rpl) { return rpl >= 16384 ? 256 : rpl >= 8192 ? 128 : rpl >= 4096 ? 64 : (rpl >= 2048 ? 32 : (rpl >= 256 ? 16 : (rpl >= 64 ? 8 : (rpl >= 16 ? 4 : (rpl >= 4 ? 2 : 1))))); }
-// A wave's 64 lanes cover this many local rows (two 16-row blocks with 2048 pixels per lane, four with 4096) ...
-constexpr int rt_raster_wave_rows(int rpl) { return rpl >= 16384 ? 16 * RT_TILE_H : rpl >= 8192 ? 8 * RT_TILE_H : rpl >= 4096 ? 4 * RT_TILE_H : (rpl >= 2048 ? 2 * RT_TILE_H : RT_TILE_H); }
-// 4096 pixels per lane (64 rows) exist only in the regular-row form of the sweep, which steps from
-// row to row by a constant instead of holding every row's coordinate in a register
-constexpr int RT_RASTER_RPL_REGULAR = 16384;
+// Wave-block form of the pixel-grid sweep (regular rows, no tile culling): a workgroup's block is 4096
+// columns by 64 NL rows, NL = 1, 2, 4, 8, 16 or 36, and "pixels per lane" = 4096 NL names the shape.
+constexpr int RT_WAVE_BLOCK_RPL = 4096;
+constexpr bool rt_wave_block_shape(int rpl)
+{
+    return rpl == 4096 || rpl == 8192 || rpl == 16384 || rpl == 32768 || rpl == 65536 || rpl == 36 * 4096;
+}
+// A lane's rpl pixels in the lattice form are a block of this many rows (by rpl / rows columns); in the
+// wave-block form: the rows of the block.
+constexpr int rt_raster_lane_rows(int rpl) { return rpl >= RT_WAVE_BLOCK_RPL ? rpl / 64 : (rpl >= 2048 ? 32 : (rpl >= 256 ? 16 : (rpl >= 64 ? 8 : (rpl >= 16 ? 4 : (rpl >= 4 ? 2 : 1))))); }
+// A wave's 64 lanes cover this many local rows (two 16-row blocks with 2048 pixels per lane) ...
+constexpr int rt_raster_wave_rows(int rpl) { return rpl >= RT_WAVE_BLOCK_RPL ? rpl / 64 : (rpl >= 2048 ? 2 * RT_TILE_H : RT_TILE_H); }
+// most pixels per lane in the regular-row forms (the wave-block form's tallest block)
+constexpr int RT_RASTER_RPL_REGULAR = 36 * 4096;
 // ... by this many pixel columns
 constexpr int rt_raster_wave_cols(int rpl) { return 64 * rpl / rt_raster_wave_rows(rpl); }
 // Hot loop of the pixel-grid sweep, per lane and triangle (rpl pixels = rows x columns): the
@@ -95,6 +102,8 @@ constexpr int rt_raster_wave_cols(int rpl) { return 64 * rpl / rt_raster_wave_ro
 struct RasterMix { int fma, add, logic, compare; };
 constexpr RasterMix rt_raster_mix(int rpl)
 {
+    // wave-block form: 64 columns and NL rows per lane (104 instructions per wave, triangle and 4096 x 256 pixels)
+    if (rpl >= RT_WAVE_BLOCK_RPL) return RasterMix{0, 64 + rpl / 4096, 32 + rpl / 8192, 2};
     return RasterMix{0, rpl / rt_raster_lane_rows(rpl) + rt_raster_lane_rows(rpl),
                      (rpl / rt_raster_lane_rows(rpl) > 1 ? rpl / rt_raster_lane_rows(rpl) / 2 : 0) +
                          (rt_raster_lane_rows(rpl) > 1 ? rt_raster_lane_rows(rpl) / 2 : 0),
@@ -170,7 +179,7 @@ struct rt_scene {
     std::vector<hipEvent_t> count_events;
 
     // per-call workspaces (grow-only)
-    DevBuf ws_cnt, ws_list, ws_ovf, ws_counters, ws_besthi, ws_partials, ws_frame;
+    DevBuf ws_cnt, ws_list, ws_ovf, ws_counters, ws_besthi, ws_partials, ws_frame, ws_axis;
     DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_act2, ws_live, ws_occid, ws_sort;
     // the cell-lattice any-hit sweep (rt_sweep_cells.hip): sort space and ray records, the cell
     // table, the triangles' boxes in cell units
@@ -358,7 +367,7 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st);     // any-hit ove
 // multiples of step_out (0: no exclusion): the levels of the occluder cache.
 // hit (or nullptr): the primary hit of every local pixel; pixels that hit nothing have no rays and
 // their slots in S and E are not read
-int rt_launch_bin_rays(const double* S, const double* E, const int32_t* hit, int W, int rows, int lights,
+int rt_launch_bin_rays(const double* S, const double* E, const int8_t* axis, const int32_t* hit, int W, int rows, int lights,
                        long stride, int step_in, int step_out, int32_t* out, int* out_counts, hipStream_t st);
 // Pixel spacing of the occluder cache's levels, coarsest first; the last must be 1.  (A third,
 // coarser level -- 16, 4, 1 -- was measured: it saves 4 % of the pair tests and loses more than
@@ -500,6 +509,7 @@ struct ShadeArgs {
     const int32_t* hit;       // per pixel (band-local)
     const double* tuv;
     double *shS, *shE;        // shadow rays: [light][pixel] 3 doubles each
+    int8_t* sh_axis;          // [light][pixel]: dominant axis of the ray's direction, -1 = no ray (written with the rays; may be nullptr)
     const uint8_t* occ;       // [light][pixel]
     double* argb;
     uint8_t* rgb8;

@@ -116,13 +116,20 @@ __global__ void __launch_bounds__(RT_WG) k_shadow_setup(const ShadeArgs a)
         double* E = a.shE + 3 * ((long)l * npix + p);
         LightGeom g;
         light_geom(f, l, point, normal, g);
+        int axis = -1;
         if (g.status == 2) {
             S[0] = g.shadow_S[0]; S[1] = g.shadow_S[1]; S[2] = g.shadow_S[2];
             E[0] = f.light_pos[l][0]; E[1] = f.light_pos[l][1]; E[2] = f.light_pos[l][2];
+            // what k_bin_rays would otherwise read both end points again for: the dominant axis of
+            // the direction, or no ray at all (unused slot, zero-length or non-finite direction)
+            const double sx = S[0];
+            const double dx = fabs(E[0] - sx), dy = fabs(E[1] - S[1]), dz = fabs(E[2] - S[2]);
+            if (sx == sx && dx + dy + dz > 0 && dx + dy + dz < 1e300) axis = dx >= dy && dx >= dz ? 0 : (dy >= dz ? 1 : 2);
         } else {
             S[0] = S[1] = S[2] = qnan;      // unused slot: the sweep skips it
             E[0] = E[1] = E[2] = 0;
         }
+        if (a.sh_axis) a.sh_axis[(long)l * npix + p] = (int8_t)axis;
     }
 }
 

@@ -567,6 +567,234 @@ k_sweep_raster(const SweepArgs A)
 }
 
 // ------------------------------------------------------------------------------------------
+// primary rays, wave-block form
+// ------------------------------------------------------------------------------------------
+// In the lattice form above with 64 rows and more per lane, every lane of a wave has the same
+// rows (its 64 lanes are 64 column phases): the wave's pixels are the product of its columns and
+// its rows, and some pixel of the WAVE lies in a triangle's box exactly when some column lies in
+// the box's x extent and some row in its y extent.  So the row half of the test need not be
+// repeated in every lane: this form deals the block's rows to the lanes as it deals the columns
+// (lane l: columns l, l + 64, ... of 4096; local rows l, l + 64, ... of 64 NL), every lane tests
+// its own, and two ballots combine them -- 64 + NL additions and 32 + NL / 2 minima per wave and
+// triangle for 4096 x 64 NL pixels (104 instructions for 4096 x 256, where a lattice of 256 rows in
+// every lane took 482).  Every column and every row is tested against every triangle, and a
+// pixel's verdict is its column's and its row's, as before.
+//
+// A workgroup owns one block; its four waves sweep a quarter of every staged tile each and note
+// which of the quarter's 32 triangles passed.  Behind that, the wave works through the passing
+// triangles' pixel rectangles together (raster_rare_batch): lane k takes triangle k's box, finds
+// its columns (an interval, from the box) and its rows (the block's rows are in ascending order
+// of Y: two binary searches with the hot loop's own comparison) and fetches its planes into LDS
+// -- one wait for memory per quarter tile -- and then the rectangles are worked through one after
+// the other, a rectangle's pixels dealt to the 64 lanes 64 at a time for the inside test of
+// finish_raster.  (Dealing the pixels of all rectangles to the lanes together, as the cell sweep
+// does with its rays, was measured and lost: 2.0 ms of rare path against 1.0 on the million-triangle
+// frame -- a search per pixel for its rectangle, and planes that differ from lane to lane.)
+constexpr int kWaveBlockCols = 4096;
+constexpr int kWaveGroup = 2;           // tiles of boxes staged at a time
+
+template <int NL>
+__device__ __forceinline__ void raster_rare_batch(const SweepArgs& A, const float4* qbox, int tri0, unsigned passed,
+                                                  int wave_x0, int wave_y0, const float* rows_y, float4 (*qp)[4],
+                                                  float Xs0, const float (&YL)[NL], int lane)
+{
+    constexpr int WW = kWaveBlockCols, WH = 64 * NL;
+    constexpr float COLS = (float)RT_RASTER_COLS;
+    int x_lo = 0, nx = 0, r_lo = 0, ny = 0;
+    const bool mine = lane < 32 && ((passed >> lane) & 1u);
+    float4 P, M, Hh, N;
+    if (mine) {
+        const float4* __restrict__ g4 = A.planes + (tri0 + lane);
+        P = g4[0];
+        M = g4[A.plane_stride];         // (.w: the margin)
+        Hh = g4[2 * A.plane_stride];
+        N = g4[3 * A.plane_stride];
+        const float4 box = qbox[lane];
+        // columns: pixels px with |(px - W/2) / COLS - cx| <= rx inside the block and the image.  The
+        // bounds are rounded inwards to whole pixels: the box was grown by 0.01 pixel and more for
+        // the roundings of a test on it, a hundred times what the bounds' own roundings come to.
+        const int x_end = wave_x0 + WW < A.W ? wave_x0 + WW : A.W;
+        const float half_w = (float)(A.W / 2);
+        const float xl = __builtin_fmaxf(__builtin_fmaf(COLS, box.x - box.y, half_w), (float)wave_x0);
+        const float xh = __builtin_fminf(__builtin_fmaf(COLS, box.x + box.y, half_w), (float)(x_end - 1));
+        if (xl <= xh) {
+            x_lo = (int)__builtin_ceilf(xl);
+            nx = (int)__builtin_floorf(xh) - x_lo + 1;
+        }
+        // rows: the local rows r with |Y_r - cy| <= ry, i.e. -ry <= Y_r - cy <= ry in the hot loop's
+        // own arithmetic.  Y ascends with r (rows beyond the band: NaN, at the end), and so does the
+        // rounded difference, so they are the rows from the first one that is not below the extent
+        // to the first one above it.
+        int lo = 0, hi = WH;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (rows_y[mid] - box.z < -box.w) lo = mid + 1;
+            else hi = mid;
+        }
+        r_lo = lo;
+        hi = WH;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (rows_y[mid] - box.z <= box.w) lo = mid + 1;
+            else hi = mid;
+        }
+        ny = lo - r_lo;
+    }
+#if RT_RASTER_CHECK_INTERVAL
+    // every column and row of the wave that passes the hot loop's test for one of these triangles
+    // must lie in the rectangle found here
+    {
+        unsigned long long missed = 0;
+        for (unsigned m = passed; m; m &= m - 1) {
+            const int k = __builtin_ctz(m);
+            const float4 box = qbox[k];
+            const int kx = __shfl(x_lo, k), knx = __shfl(nx, k), kr = __shfl(r_lo, k), kny = __shfl(ny, k);
+            const float d0 = Xs0 - box.x;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) {
+                const int px = wave_x0 + lane + 64 * c;
+                if (__builtin_fabsf(d0 + (64.0f / COLS) * (float)c) <= box.y && px < A.W && !(px >= kx && px < kx + knx)) ++missed;
+            }
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int lrow = lane + 64 * j;
+                if (__builtin_fabsf(YL[j] - box.z) <= box.w && wave_y0 + lrow < A.rows.rows && !(lrow >= kr && lrow < kr + kny)) ++missed;
+            }
+        }
+        if (missed && A.tests) atomicAdd(A.tests, missed << 48);
+    }
+#endif
+    if (nx <= 0 || ny <= 0) nx = ny = 0;
+    const int npix = nx * ny;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(npix > 0);
+    if (todo == 0) return;
+    if (mine) {
+        qp[lane][0] = P;
+        qp[lane][1] = M;
+        qp[lane][2] = Hh;
+        qp[lane][3] = N;
+    }
+    // one rectangle after the other, its pixels dealt to the lanes 64 at a time (rectangle and
+    // planes are wave-uniform: scalar registers and LDS broadcasts)
+    for (; todo; todo &= todo - 1) {
+        const int k = __builtin_ctzll(todo);
+        const int knx = __builtin_amdgcn_readlane(nx, k), kx = __builtin_amdgcn_readlane(x_lo, k);
+        const int kr = __builtin_amdgcn_readlane(r_lo, k), kn = __builtin_amdgcn_readlane(npix, k);
+        const float4 kP = qp[k][0], kH = qp[k][2], kN = qp[k][3];
+        const float margin = qp[k][1].w;
+        const float inv = __builtin_amdgcn_rcpf((float)knx);
+        for (int q = lane; q < kn; q += 64) {
+            // q = r knx + c: the quotient from a reciprocal, put right by one where it is off
+            int r = (int)(((float)q + 0.5f) * inv);
+            int c = q - r * knx;
+            if (c < 0) { --r; c += knx; }
+            else if (c >= knx) { ++r; c -= knx; }
+            const int row = kr + r, px = kx + c;
+            finish_raster(A, (long)(wave_y0 + row) * A.W + px, tri0 + k, kP, margin, kH, kN,
+                          (float)(px - A.W / 2) * (1.0f / COLS), rows_y[row]);
+        }
+    }
+}
+
+template <int NL>
+__global__ void __launch_bounds__(RT_WG, RT_RASTER_WAVES)
+k_sweep_raster_wave(const SweepArgs A)
+{
+    constexpr int WW = kWaveBlockCols, WH = 64 * NL;
+    constexpr float COLS = (float)RT_RASTER_COLS, KX = 64.0f / COLS;
+    // (one more entry: the read-ahead touches the one behind the second buffer)
+    __shared__ float4 tile_lds[2 * kWaveGroup * RT_TILE + 1];
+    auto tile = reinterpret_cast<float4 (*)[kWaveGroup * RT_TILE]>(tile_lds);
+    __shared__ float row_y[WH];                                 // driver.c:132 per local row of the block, NaN beyond the band
+    __shared__ float4 plane_lds[RT_WG / 64][RT_TILE / 4][4];    // the rare path's planes of a quarter tile, per wave
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int cols = (A.W + WW - 1) / WW;
+    const int wy = (int)blockIdx.x / cols;
+    const int wave_x0 = ((int)blockIdx.x - wy * cols) * WW, wave_y0 = wy * WH;
+    auto y_of = [&](int r) {
+        return wave_y0 + r < A.rows.rows ? (float)(A.rows.image_row(wave_y0 + r) - A.H / 2) : __builtin_nanf("");
+    };
+    for (int r = tid; r < WH; r += RT_WG) row_y[r] = y_of(r);
+    float YL[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) YL[j] = y_of(lane + 64 * j);
+    // column c of the lane has X = wave_x0 + lane + 64 c - W/2 (driver.c:131); the boxes are in units
+    // of COLS pixels, so the sweep works with X / COLS = Xs0 + (64 / COLS) c (exact in fp32)
+    const float Xs0 = (float)(wave_x0 + lane - A.W / 2) * (1.0f / COLS);
+
+    // this workgroup's share of the triangle range: chunk blockIdx.y of gridDim.y
+    const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
+    const int t_begin = t_first + (int)((long)t_count * blockIdx.y / gridDim.y);
+    const int t_end = t_first + (int)((long)t_count * (blockIdx.y + 1) / gridDim.y);
+    const float4* __restrict__ boxes = A.planes + (long)RT_APEX_PLANES * A.plane_stride;
+    auto group = [&](int t) { return t_end - t < kWaveGroup ? t_end - t : kWaveGroup; };
+    auto stage = [&](int t, int count, float4* buf) {
+        const float4* src = boxes + (long)t * RT_TILE;
+        // (RT_TILE / 64 parts of 64 boxes per tile, dealt to the four waves)
+#pragma unroll
+        for (int c = 0; c < (kWaveGroup * (RT_TILE / 64) + 3) / 4; ++c) {
+            const int part = c * 4 + wave;
+            if (part < count * (RT_TILE / 64))
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + part * 64 + lane),
+                    (__attribute__((address_space(3))) void*)&buf[part * 64], 16, 0, 0);
+        }
+    };
+    unsigned long long tiles_done = 0;
+    if (t_begin < t_end) stage(t_begin, group(t_begin), tile[0]);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();            // (the staged boxes and row_y)
+    int round = 0;
+    for (int t = t_begin; t < t_end; t += kWaveGroup, ++round) {
+        const int buf = round & 1, count = group(t);
+        if (t + kWaveGroup < t_end) stage(t + kWaveGroup, group(t + kWaveGroup), tile[buf ^ 1]);
+        const float4* __restrict__ base = tile[buf];
+        for (int sub = 0; sub < count; ++sub) {
+            // this wave's quarter of the tile (the address in a vector register the compiler cannot see
+            // through, advanced once per kRasterUnroll triangles, the reads at immediate offsets, one
+            // triangle ahead; the last read of a quarter touches the entry behind it and is not used)
+            const float4* qbox = base + sub * RT_TILE + wave * (RT_TILE / 4);
+            const int tri0 = (t + sub) * RT_TILE + wave * (RT_TILE / 4);
+            unsigned box_at = lds_address(qbox);
+            asm volatile("" : "+v"(box_at));
+            float4 next = lds_read_float4(box_at);
+            unsigned passed = 0;
+            for (int j4 = 0; j4 < RT_TILE / 4; j4 += kRasterUnroll) {
+#pragma unroll
+                for (int k = 0; k < kRasterUnroll; ++k) {
+                    const float4 box = next;
+                    next = lds_read_float4(box_at + 16u * (unsigned)(k + 1));
+                    const float d0 = Xs0 - box.x;
+                    float accx = INF;
+#pragma unroll
+                    for (int c = 0; c + 1 < 64; c += 2)     // (d0 + 0.0f is not d0 to the compiler: it would keep the addition)
+                        accx = min3_abs(accx, c == 0 ? d0 : d0 + KX * (float)c, d0 + KX * (float)(c + 1));
+                    float accy = NL == 1 ? __builtin_fabsf(YL[0] - box.z) : INF;
+#pragma unroll
+                    for (int j = 0; j + 1 < NL; j += 2) accy = min3_abs(accy, YL[j] - box.z, YL[j + 1] - box.z);
+                    const bool in = __builtin_amdgcn_ballot_w64(accx <= box.y) != 0 &&
+                                    __builtin_amdgcn_ballot_w64(accy <= box.w) != 0;
+                    if (in) passed |= 1u << (j4 + k);
+                }
+                box_at += 16u * kRasterUnroll;
+            }
+            if (__builtin_expect(passed != 0 && A.debug_skip != 1, 0))
+                raster_rare_batch<NL>(A, qbox, tri0, passed, wave_x0, wave_y0, row_y, plane_lds[wave], Xs0, YL, lane);
+        }
+        tiles_done += count;
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    }
+    // pairs tested: this wave's quarter of every tile against the block's pixels
+    if (A.tests && lane == 0)
+        atomicAdd(A.tests, tiles_done * (unsigned long long)(RT_TILE / 4) * ((unsigned long long)WW * WH));
+}
+
+// ------------------------------------------------------------------------------------------
 // any-hit sweep for rays that end at the apex (shadow rays of one light)
 // ------------------------------------------------------------------------------------------
 // The bounding-square and inside tests do not change when the direction is scaled by any non-zero
@@ -1002,15 +1230,16 @@ k_sweep_apex(SweepArgs A)
 // the screen (they tend to retire together).  Unused slots (NaN origin) are left out, and
 // step_in / step_out select the rays of one level of the occluder cache.
 __global__ void __launch_bounds__(RT_WG)
-k_bin_rays(const double* __restrict__ S, const double* __restrict__ E, const int32_t* __restrict__ hit,
-           int W, int rows, long stride, int step_in, int step_out, int32_t* __restrict__ out,
-           int* __restrict__ out_counts)
+k_bin_rays(const double* __restrict__ S, const double* __restrict__ E, const int8_t* __restrict__ axis,
+           const int32_t* __restrict__ hit, int W, int rows, long stride, int step_in, int step_out,
+           int32_t* __restrict__ out, int* __restrict__ out_counts)
 {
     __shared__ int s_wave[RT_WG / 64][3];
     __shared__ int s_base[3];
     const long light = blockIdx.y;
     S += 3 * light * stride;
     E += 3 * light * stride;
+    if (axis) axis += light * stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tiles_x = (W + 63) / 64, tiles_y = (rows + 15) / 16;
     const long total = (long)tiles_x * tiles_y * 1024;
@@ -1029,6 +1258,7 @@ k_bin_rays(const double* __restrict__ S, const double* __restrict__ E, const int
         if (step_out > 0 && px % step_out == 0 && lr % step_out == 0) return -1;
         id = lr * W + px;
         if (hit && hit[id] < 0) return -1;          // the pixel hit nothing: its ray slots were never written
+        if (axis) return (int)axis[id];             // (the same classification, made when the ray was)
         const double* s = S + 3 * (long)id;
         const double* en = E + 3 * (long)id;
         const double sx = s[0];
@@ -1147,6 +1377,7 @@ int rt_device_cus()
 // every kernel shape on small inputs).
 void rt_raster_shape(int W, int rows, int tiles, bool regular, int* pixels_per_lane, int* chunks, int* waves_x)
 {
+    const bool wave_form = regular && !rt_tile_culling();       // the wave-block form is available
     const long slots = (regular ? 8L : 5L) * rt_device_cus();      // resident workgroups
     int max_chunks = tiles;                            // a chunk may be a single tile
     if (max_chunks < 1) max_chunks = 1;
@@ -1154,50 +1385,69 @@ void rt_raster_shape(int W, int rows, int tiles, bool regular, int* pixels_per_l
     static const int env_cap = getenv("RT_AMD_RASTER_MAX_CHUNKS") ? atoi(getenv("RT_AMD_RASTER_MAX_CHUNKS")) : 0;
     const long cap = env_cap > 0 ? env_cap : RT_RASTER_MAX_CHUNKS;
     if (max_chunks > cap) max_chunks = (int)cap;
-    // pixels the workgroup tiles cover, and the wave layout that covers the fewest (waves wholly
-    // beyond the image's edges do no arithmetic, but they hold registers and LDS)
     // pixels the working waves cover: what the arithmetic is paid for
     auto swept = [&](int r) { return rt_raster_pairs(W, rows, r, 1); };
-    // the row-by-row dealing of the waves leaves at most three of them idle in the whole launch
-    // (an idle wave does no arithmetic but keeps its slot on a SIMD whose issue rate needs all
-    // eight); the rectangular layouts remain for forced shapes
-    // ... and the regular-row form gives every wave-sized block a workgroup of its own (no idle wave at all)
-    auto best_layout = [&](int) { return regular && !rt_tile_culling() ? -1 : 0; };
-    // most pixels per lane this call can use: 4096 (64 rows) only in the regular-row form, and not
-    // with tile culling
-    const int rpl_max = regular && !rt_tile_culling() ? RT_RASTER_RPL_REGULAR : RT_RASTER_RPL;
+    // the lattice form in regular rows gives every wave-sized block a workgroup of its own (no idle
+    // wave at all); otherwise the waves are dealt row by row, which leaves at most three idle in the
+    // whole launch; the rectangular layouts remain for forced shapes
+    auto best_layout = [&](int) { return wave_form ? -1 : 0; };
+    static const int rounds = getenv("RT_AMD_RASTER_ROUNDS") ? atoi(getenv("RT_AMD_RASTER_ROUNDS")) : 24;
     if (const char* force = getenv("RT_AMD_RASTER_FORCE")) {
         int fr = 0, fc = 0, fw = 0;
         const int n = sscanf(force, "%d,%d,%d", &fr, &fc, &fw);
-        if (n >= 2 && fc >= 1 && fc <= (tiles < 1 ? 1 : tiles) &&
-            (fr == 1 || fr == 2 || fr == 4 || fr == 8 || fr == 16 || fr == 32 || fr == 64 || fr == 128 || fr == 256 ||
-             fr == 512 || fr == 1024 || fr == 2048 || fr == 4096 || fr == 8192 || fr == 16384) &&
-            fr <= rpl_max) {
+        const bool lattice = fr >= 1 && fr <= RT_RASTER_RPL && (fr & (fr - 1)) == 0;
+        const bool block = wave_form && rt_wave_block_shape(fr);
+        if (n >= 2 && fc >= 1 && fc <= (tiles < 1 ? 1 : tiles) && (lattice || block)) {
             *pixels_per_lane = fr;
             *chunks = fc;
-            *waves_x = (n == 3 && (fw == -1 || fw == 0 || fw == 1 || fw == 2 || fw == 4)) ? fw : best_layout(fr);
+            *waves_x = block ? -1 : ((n == 3 && (fw == -1 || fw == 0 || fw == 1 || fw == 2 || fw == 4)) ? fw : best_layout(fr));
             return;
         }
     }
-    // (with tile culling a wave's pixel rectangle should not be too wide: the narrower, the fewer
-    // triangles survive its test; 32 pixels per lane measured best on a 1 M-triangle 4K frame)
-    int r = rt_tile_culling() && RT_RASTER_RPL > 32 ? 32 : rpl_max;
-    // The wider and taller a wave's pixels (a lane of 1024 pixels has 64 columns of 16 rows, the wave
-    // is 4096 x 16 pixels; a lane of 16384 has 256 rows), the fewer instructions a pair costs, and
-    // the more often the wave has a pixel inside a triangle's box and enters the rare path.  How
-    // often depends on the size of the triangles on the screen, for which their number stands in.
-    // In the regular-row form the wave walks a passing box's pixels together and the rare path is
-    // cheap; measured at 3840x2160: a million triangles sweep in 7.1 ms with 4096 pixels per lane,
-    // 5.6 with 8192, 5.1 with 16384; 100 000 (a torus) in 2.16 ms with 512, 1.75 (1024), 1.11 (2048),
-    // 0.85 (4096), 0.88 (8192), 0.96 (16384); 69 000 (a sphere) in 1.67 (512), 0.98 (2048), 0.88 (4096),
-    // 0.90 (8192); 6 000 in 0.56 (128), 0.50 (512), 0.57 (1024), 0.95 (2048).  In the other forms every
-    // lane walks its own columns and rows: a million triangles in 12.7 ms with 2048 pixels per lane,
-    // 17.4 with 1024, 20.6 with 512; 100 000 in 3.4 (1024), 2.7 (512), 3.9 ms (256); 6 000 fastest with 128.
-    static const int rows256_tiles = getenv("RT_AMD_RASTER_ROWS256_TILES") ? atoi(getenv("RT_AMD_RASTER_ROWS256_TILES")) : 4096;
-    static const int rows64_tiles = getenv("RT_AMD_RASTER_ROWS64_TILES") ? atoi(getenv("RT_AMD_RASTER_ROWS64_TILES")) : 256;
-    const int widest = rpl_max > RT_RASTER_RPL
-                           ? (tiles >= rows256_tiles ? 16384 : tiles >= rows64_tiles ? 4096 : tiles >= 32 ? 1024 : 128)
-                           : (tiles >= 4096 ? 2048 : (tiles >= 256 ? 512 : 128));
+    // Wave-block form: a workgroup per block of 4096 columns by 64 NL rows, its hot loop 98 + 1.5 NL
+    // instructions per wave and triangle whatever the image's width.  The taller the block, the fewer
+    // blocks and the cheaper the hot loop, and the more triangles go on to the rare path (all of
+    // them, with one block for the image) -- which works through them 32 at a time and is what the
+    // launch's time then is.  Measured at 3840x2160, a million triangles: 4.9 ms per launch as a
+    // lattice of 256 rows in every lane, 2.25 ms as 4096 x 256 blocks.  The launch needs two rounds of
+    // workgroups from blocks x chunks; a mesh too small for that even with 64-row blocks keeps the
+    // lattice form below, where the pixels supply the workgroups.
+    if (wave_form) {
+        static const int shapes[] = {36, 16, 8, 4, 2, 1};
+        int best = 0;
+        double best_cost = 0;
+        for (int nl : shapes) {
+            const int r = RT_WAVE_BLOCK_RPL * nl;
+            const long wgs = rt_raster_tiles(W, rows, r, -1);
+            if (wgs * max_chunks < 2 * slots) continue;
+            const double cost = (double)wgs * (98.0 + 1.5 * nl);
+            if (!best || cost < best_cost) {
+                best = r;
+                best_cost = cost;
+            }
+        }
+        if (best) {
+            const long wgs = rt_raster_tiles(W, rows, best, -1);
+            long c = (rounds * slots + wgs - 1) / wgs;
+            if (c > max_chunks) c = max_chunks;
+            *pixels_per_lane = best;
+            *chunks = c < 1 ? 1 : (int)c;
+            *waves_x = -1;
+            return;
+        }
+    }
+    // Lattice form.  (With tile culling a wave's pixel rectangle should not be too wide: the narrower,
+    // the fewer triangles survive its test; 32 pixels per lane measured best on a 1 M-triangle 4K frame.)
+    int r = rt_tile_culling() && RT_RASTER_RPL > 32 ? 32 : RT_RASTER_RPL;
+    // The wider a wave's pixels (a lane of 1024 pixels has 64 columns of 16 rows, the wave is 4096 x 16
+    // pixels), the fewer instructions a pair costs, and the more often the wave has a pixel inside a
+    // triangle's box and enters the rare path.  How often depends on the size of the triangles on
+    // the screen, for which their number stands in.  Measured at 3840x2160 in the regular-row form
+    // (the wave walks a passing box's pixels together): 6 000 triangles sweep in 0.56 ms with 128
+    // pixels per lane, 0.50 (512), 0.57 (1024), 0.95 (2048).  In the other forms every lane walks its
+    // own columns and rows: a million triangles in 12.7 ms with 2048 pixels per lane, 17.4 with 1024,
+    // 20.6 with 512; 100 000 in 3.4 (1024), 2.7 (512), 3.9 ms (256); 6 000 fastest with 128.
+    const int widest = wave_form ? (tiles >= 32 ? 1024 : 128) : (tiles >= 4096 ? 2048 : (tiles >= 256 ? 512 : 128));
     if (r > widest) r = widest;
     while (r > 1 && rt_raster_wave_cols(r) > W + rt_raster_wave_cols(r) / 2) r /= 2;    // no wave mostly off the image
     // more pixels per lane cost fewer instructions per pair, but their wider tiles may cover
@@ -1219,7 +1469,6 @@ void rt_raster_shape(int W, int rows, int tiles, bool regular, int* pixels_per_l
         const int wx = best_layout(r);
         const long wgs = rt_raster_tiles(W, rows, r, wx);
         if (wgs * max_chunks >= slots || r == 1) {
-            static const int rounds = getenv("RT_AMD_RASTER_ROUNDS") ? atoi(getenv("RT_AMD_RASTER_ROUNDS")) : 24;
             long c = (rounds * slots + wgs - 1) / wgs;  // about 24 rounds are fine-grained enough
             if (c > max_chunks) c = max_chunks;
             // (a workgroup of wide lanes has more to set up: its chunks keep two tiles)
@@ -1264,9 +1513,22 @@ int rt_launch_sweep_raster(const SweepArgs& a, hipStream_t st)
         return a.cull ? launch(k_sweep_raster<n, true, false>, a, grid, st, "raster sweep (tile culling)")  \
                       : (regular ? launch(k_sweep_raster<n, false, true>, a, grid, st, "raster sweep")     \
                                  : launch(k_sweep_raster<n, false, false>, a, grid, st, "raster sweep"));
-    if (r == 4096 && regular && !a.cull) return launch(k_sweep_raster<4096, false, true>, a, grid, st, "raster sweep");
-    if (r == 8192 && regular && !a.cull) return launch(k_sweep_raster<8192, false, true>, a, grid, st, "raster sweep");
-    if (r == 16384 && regular && !a.cull) return launch(k_sweep_raster<16384, false, true>, a, grid, st, "raster sweep");
+    if (r >= RT_WAVE_BLOCK_RPL) {       // wave-block form: 4096 columns by 64 NL rows per workgroup
+        if (!regular || a.cull || wx != -1) {
+            rt_set_error("raster sweep: %d pixels per lane exist in the wave-block form only", r);
+            return RT_E_ARG;
+        }
+        switch (r / RT_WAVE_BLOCK_RPL) {
+        case 1: return launch(k_sweep_raster_wave<1>, a, grid, st, "raster sweep");
+        case 2: return launch(k_sweep_raster_wave<2>, a, grid, st, "raster sweep");
+        case 4: return launch(k_sweep_raster_wave<4>, a, grid, st, "raster sweep");
+        case 8: return launch(k_sweep_raster_wave<8>, a, grid, st, "raster sweep");
+        case 16: return launch(k_sweep_raster_wave<16>, a, grid, st, "raster sweep");
+        case 36: return launch(k_sweep_raster_wave<36>, a, grid, st, "raster sweep");
+        }
+        rt_set_error("raster sweep: unsupported pixels per lane %d", r);
+        return RT_E_ARG;
+    }
     switch (r) {
         RT_RASTER_CASE(1)
         RT_RASTER_CASE(2)
@@ -1396,8 +1658,8 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
     return RT_E_ARG;
 }
 
-int rt_launch_bin_rays(const double* S, const double* E, const int32_t* hit, int W, int rows, int lights,
-                       long stride, int step_in, int step_out, int32_t* out, int* out_counts, hipStream_t st)
+int rt_launch_bin_rays(const double* S, const double* E, const int8_t* axis, const int32_t* hit, int W, int rows,
+                       int lights, long stride, int step_in, int step_out, int32_t* out, int* out_counts, hipStream_t st)
 {
     if (W <= 0 || rows <= 0 || lights <= 0) return RT_OK;
     if (step_in < 1 || step_out < 0) {
@@ -1407,7 +1669,7 @@ int rt_launch_bin_rays(const double* S, const double* E, const int32_t* hit, int
     const long total = (long)((W + 63) / 64) * ((rows + 15) / 16) * 1024;
     long wgs = (total + RT_WG - 1) / RT_WG;
     if (wgs > 2048) wgs = 2048;
-    hipLaunchKernelGGL(k_bin_rays, dim3((unsigned)wgs, lights), dim3(RT_WG), 0, st, S, E, hit, W, rows,
+    hipLaunchKernelGGL(k_bin_rays, dim3((unsigned)wgs, lights), dim3(RT_WG), 0, st, S, E, axis, hit, W, rows,
                        stride, step_in, step_out, out, out_counts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

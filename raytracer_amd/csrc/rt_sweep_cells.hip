@@ -92,29 +92,6 @@ __device__ __forceinline__ bool finish_cell(const CellArgs& A, const CellCtx& X,
     return false;
 }
 
-// Running sum over the wave's 64 lanes (inclusive).
-__device__ __forceinline__ int wave_scan(int v, int lane)
-{
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(v, off);
-        v += lane >= off ? t : 0;
-    }
-    return v;
-}
-
-// The first lane whose running sum `incl` exceeds r (63 when none does).
-__device__ __forceinline__ int wave_search(int incl, int r)
-{
-    int l = 0;
-#pragma unroll
-    for (int step = 32; step > 0; step >>= 1) {
-        const int v = __shfl(incl, l + step - 1);
-        l += v <= r ? step : 0;
-    }
-    return l > 63 ? 63 : l;
-}
-
 // The rare path, for the triangles of a quarter tile (32 of them) that had some cell of the wave
 // inside their grown box -- `passed`, one bit each.  The cells of the wave's footprint whose
 // centre is in a triangle's box form a rectangle of the grid, and because the rays are sorted by

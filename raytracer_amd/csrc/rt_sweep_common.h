@@ -162,4 +162,27 @@ __device__ __forceinline__ bool candidate_shared(int32_t* __restrict__ cnt_slot,
     return false;
 }
 
+// Running sum over the wave's 64 lanes (inclusive).
+__device__ __forceinline__ int wave_scan(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(v, off);
+        v += lane >= off ? t : 0;
+    }
+    return v;
+}
+
+// The first lane whose running sum `incl` exceeds r (63 when none does).
+__device__ __forceinline__ int wave_search(int incl, int r)
+{
+    int l = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+        const int v = __shfl(incl, l + step - 1);
+        l += v <= r ? step : 0;
+    }
+    return l > 63 ? 63 : l;
+}
+
 }  // namespace rt_sweep

@@ -460,7 +460,8 @@ def test_triangles_whose_plane_contains_a_light():
                                    "32,1", "32,2,2", "32,3,1", "64,1", "64,2,1", "64,3,4", "128,1", "128,3,2", "128,2,1",
                                    "256,1", "256,2,4", "256,5,1", "512,1", "512,3,0", "1024,1", "1024,2,0", "1024,4,1", "2048,1", "2048,3,0", "2048,2,1",
                                    "4096,1", "4096,3,0", "4096,2,1", "4096,3,-1", "2048,2,-1", "256,2,-1", "16,3,-1", "1,2,-1",
-                                   "8192,1", "8192,2,-1", "8192,3,1", "16384,1", "16384,3,-1", "16384,2,0"])
+                                   "8192,1", "8192,2,-1", "8192,3,1", "16384,1", "16384,3,-1", "16384,2,0",
+                                   "32768,2", "65536,1", "65536,5,-1", "147456,1", "147456,3,-1"])
 @pytest.mark.parametrize("W,H", [(500, 20), (37, 19), (200, 150), (90, 600)])
 @pytest.mark.parametrize("regular", [None, "0"])
 def test_every_shape_of_the_pixel_grid_sweep(shape, W, H, monkeypatch, regular):
@@ -469,10 +470,11 @@ def test_every_shape_of_the_pixel_grid_sweep(shape, W, H, monkeypatch, regular):
     pixels are partly or wholly off the image, chunks of uneven length, the four waves of a
     workgroup side by side, two by two or stacked) and compare with the oracle.  Each shape in
     both forms of the kernel: rows stepped by a constant (the default where the rows of the
-    call are regular, and the only form with 64, 128 or 256 rows per lane), and a coordinate per
-    row.  The 600-row image gives the tall lanes several row groups and a second block of rows."""
-    if regular == "0" and shape.split(",")[0] in ("4096", "8192", "16384"):
-        pytest.skip("64 and more rows per lane exist in the regular-row form only")
+    call are regular, and the only one with blocks of 64 to 2304 rows -- the wave-block form, whose
+    workgroups always own one block each), and a coordinate per row.  The 600-row image gives the tall
+    blocks several row groups and a second block of rows."""
+    if regular == "0" and int(shape.split(",")[0]) >= 4096:
+        pytest.skip("blocks of 64 rows and more exist in the regular-row form only")
     if H == 600 and int(shape.split(",")[0]) < 1024:
         pytest.skip("the tall image is for the tall lanes")
     if regular is not None:

@@ -34,7 +34,7 @@ for mesh in meshes:
 """
 
 
-@pytest.mark.parametrize("shape", [None, "256,3,0", "512,2,0", "1024,3,0", "2048,2,0", "4096,2,0", "4096,5,-1", "8192,3,-1", "16384,4,-1", "16384,2,0", "512,3,-1", "128,4,1", "64,4,1", "32,4,2",
+@pytest.mark.parametrize("shape", [None, "256,3,0", "512,2,0", "1024,3,0", "2048,2,0", "4096,2,0", "4096,5,-1", "8192,3,-1", "16384,4,-1", "16384,2,0", "32768,3", "65536,2", "147456,4", "512,3,-1", "128,4,1", "64,4,1", "32,4,2",
                                    "16,3,4", "8,2,1", "32,5,0", "2048,2,0/0", "256,3,0/0", "16,3,4/0"])
 def test_no_pass_outside_the_interval(shape):
     if not os.path.exists(CHECK_LIB):
