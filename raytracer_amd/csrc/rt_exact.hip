@@ -399,10 +399,21 @@ k_try_cached(ExactScene es, const double* __restrict__ Sa, const double* __restr
         if (wy < first) wy = first;
         // the recorded triangles around the ray first, all loads in flight together (tried one after
         // the other, each look-up waited for the previous test: up to NB2 memory round trips in a row)
+        // ... nearest samples first (the corners of the ray's own cell of the sample grid, then the
+        // ring around them): what occludes a ray is most often what occludes its nearest neighbours
         int tried[NB2];
 #pragma unroll
         for (int k = 0; k < NB2; ++k) {
-            const int kx = k % NB, ky = k / NB;
+            // position k of the try order -> (kx, ky) in the window: the inner (NB - 2 LO)^2 block first
+            int kx, ky;
+            if (NB == 4) {
+                constexpr int order[16] = {5, 6, 9, 10, 1, 2, 4, 7, 8, 11, 13, 14, 0, 3, 12, 15};
+                kx = order[k % 16] % NB;
+                ky = order[k % 16] / NB;
+            } else {
+                kx = k % NB;
+                ky = k / NB;
+            }
             const int qx = sx + (kx - LO) * step, qy = wy + ky * step;
             tried[k] = (qx < 0 || qx >= W || qy > last) ? -1 : occ_id[(long)qy * W + qx];
         }

@@ -15,7 +15,7 @@ bash tools/profile_bench.sh "$out/bench" > "$out/bench_run.log" 2>&1 || { tail -
 tail -12 "$out/bench_run.log"
 
 step "issue counters of the primary sweep"
-KPAT=k_sweep_raster bash tools/profile_cells.sh "$out/raster" > "$out/raster_counters.txt" 2>&1 || exit 1
+KPAT=k_sweep_raster_wave bash tools/profile_cells.sh "$out/raster" > "$out/raster_counters.txt" 2>&1 || exit 1
 tail -8 "$out/raster_counters.txt"
 
 step "issue counters of the cell sweeps"
