@@ -12,7 +12,9 @@ Prints ONE JSON line on rank 0.  `value` is whole-job Mrays/s (primary + shadow 
 frame divided by the frame time).  Along ride: pairs decided per second and the roofline of the
 sweeps (timed with HIP events on their launch stream inside the library; a "test" of the
 pixel-grid and cell-lattice sweeps is a (ray, triangle) pair DECIDED -- most of them by a
-separable box test shared by a lane's lattice -- not a pair evaluated on its own), the general
+separable box test shared by the rows and columns of a block of pixels or direction cells -- not a
+pair evaluated on its own; `roofline.bound` and `roofline.hot_loop_only_ms` say how much of the
+primary launch that test is), the general
 Moller-Trumbore sweep on the same rays (`roofline.general_mt`: every pair evaluated on its own
 in fp32 FMAs), and a CPU-oracle baseline timed on this host.
 

@@ -29,18 +29,23 @@
 //                   with survivor compaction in between, triangle chunks that share a ray's
 //                   state through atomics, an occluder cache in front (host side:
 //                   trace_shadow_rays in rt_api.hip).
-//   k_sweep_raster  closest hit for the pixel grid.  D = (X, Y, ez) with integer X, Y and a
-//                   constant ez that k_pack_apex folds into the z components.  Each lane owns
-//                   up to 4096 pixels, a lattice of rows and columns of the image.
+//   k_sweep_raster  closest hit for the pixel grid, lattice form.  D = (X, Y, ez) with integer X, Y
+//                   and a constant ez that k_pack_apex folds into the z components.  Each lane
+//                   owns up to 2048 pixels, a lattice of rows and columns of the image.
 //                   First test of a pair: the pixel against the bounding box of the
 //                   triangle's projection onto the image plane (k_pack_apex writes one per
 //                   triangle, allowances included).  A pixel is in the box when its column is
 //                   in the box's x extent and its row in the y extent, so a lane evaluates one
-//                   interval test per column and per row of its lattice -- 194 VALU instructions
-//                   per 4096 pairs (64 columns, 64 rows) -- and every pixel's verdict is the one it
+//                   interval test per column and per row of its lattice -- 146 VALU instructions
+//                   per 2048 pairs (64 columns, 32 rows) -- and every pixel's verdict is the one it
 //                   would get on its own.  Primary rays leave P, which fixes the sign of det for a
 //                   hit, so k_pack_apex orients every triangle (sign layout) for the rare path's
 //                   inside test.
+//   k_sweep_raster_wave   the same test one level up, the default for meshes large enough to
+//                   fill the machine with it: a workgroup owns a block of 4096 columns by up to
+//                   2304 rows, and the block's columns AND rows are dealt to the lanes of a wave
+//                   (the block's pixels are the product of the two) -- 98 + 1.5 NL instructions
+//                   per wave and triangle for 4096 x 64 NL pixels.
 //
 // The sweeps stream what their first test reads through LDS in tiles of RT_TILE triangles,
 // double-buffered by LDS-DMA loads and read at wave-uniform addresses (broadcast, no bank
@@ -71,7 +76,7 @@
 #define RT_RASTER_UNROLL 4
 #endif
 #ifndef RT_RASTER_CHECK_INTERVAL
-#define RT_RASTER_CHECK_INTERVAL 0   // debug: count slab passes the rare path's interval would miss
+#define RT_RASTER_CHECK_INTERVAL 0   // checking build: count columns and rows that pass the first test outside the rare path's rectangle
 #endif
 #ifndef RT_RASTER_WAVES
 #define RT_RASTER_WAVES 8   // waves per SIMD the pixel-grid sweep must fit (64 registers: the rare path
