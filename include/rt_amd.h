@@ -295,6 +295,14 @@ int rt_raster_sweep_mix(int* pixels_per_lane, int* fma, int* add, int* logic, in
  * bands, and interleaved parts whose block height is a multiple of 16) or the one that holds a
  * coordinate per row. */
 int rt_raster_sweep_form(int* regular_rows);
+/* The launch shape the primary sweep would take for a W x rows band over `triangles` triangles
+ * (host logic only, no device work): pixels per lane (4096 NL and more = the wave-block form with
+ * blocks of 4096 x 64 NL pixels, NL = 1, 2, 4, 8, 16, 36; up to 2048 = the lattice form), the
+ * triangle chunks, the wave layout (-1 = a workgroup per block, 0 = waves dealt row by row, 1 / 2 /
+ * 4 = waves side by side), and the workgroups of pixels that shape needs.  regular_rows: whether
+ * the band's rows are regular (rt_raster_sweep_form).  Honours RT_AMD_RASTER_FORCE like the sweep. */
+int rt_raster_shape_query(int W, int rows, int triangles, int regular_rows, int* pixels_per_lane,
+                          int* chunks, int* waves_x, long* pixel_workgroups);
 /* Tile culling (off by default).  The first test of every (ray, triangle) pair is the ray against
  * the bounding box of the triangle's projection (on the image plane for primary rays, on the
  * plane of the dominant axis through the light for shadow rays).  With culling on, every

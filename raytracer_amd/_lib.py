@@ -139,6 +139,8 @@ SIGNATURES = {
                                        C.POINTER(C.c_double), c_int_p]),
     "rt_raster_sweep_mix": (C.c_int, [c_int_p] * 5),
     "rt_raster_sweep_form": (C.c_int, [c_int_p]),
+    "rt_raster_shape_query": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p,
+                                        C.POINTER(C.c_long)]),
     "rt_set_tile_culling": (C.c_int, [C.c_int]),
     "rt_get_tile_culling": (C.c_int, []),
     "rt_profile_enable": (C.c_int, [C.c_int]),

@@ -146,6 +146,20 @@ extern "C" int rt_raster_sweep_mix(int* pixels_per_lane, int* fma, int* add, int
     return RT_OK;
 }
 
+extern "C" int rt_raster_shape_query(int W, int rows, int triangles, int regular_rows, int* pixels_per_lane,
+                                     int* chunks, int* waves_x, long* pixel_workgroups)
+{
+    RT_ARG(W > 0 && rows > 0 && triangles >= 0, "bad size");
+    int r = 1, c = 1, wx = 0;
+    const int tiles = (triangles + RT_TILE - 1) / RT_TILE;
+    rt_raster_shape(W, rows, tiles < 1 ? 1 : tiles, regular_rows != 0, &r, &c, &wx);
+    if (pixels_per_lane) *pixels_per_lane = r;
+    if (chunks) *chunks = c;
+    if (waves_x) *waves_x = wx;
+    if (pixel_workgroups) *pixel_workgroups = rt_raster_tiles(W, rows, r, wx);
+    return RT_OK;
+}
+
 extern "C" int rt_raster_sweep_form(int* regular_rows)
 {
     if (regular_rows) *regular_rows = rt_g().last_raster_regular.load();
