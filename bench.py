@@ -444,16 +444,18 @@ def main() -> None:
         sh_ms, sh_tests = prof.shadow_ms, float(prof.shadow_tests)
         sh_rate = sh_tests / (sh_ms * 1e-3) if sh_ms > 0 else 0.0
         if prof.cell_launches > 0:
-            # Sweeps over lattices of direction cells.  The hot loop executes one separable test per
-            # (cell, triangle) pair -- an addition per column and per row of a lane's lattice, a
-            # three-way minimum per two of either, two compares.  The library keeps the lattice
+            # Sweeps over lattices of direction cells.  The hot loop decides every (cell, triangle) pair
+            # of a wave's footprint through a separable test -- an addition per column and per row of
+            # the footprint (dealt to the lanes), a three-way minimum per two of either, two compares.  The library keeps the lattice
             # coarse (a few footprints per set of rays), so that loop only tells which triangles come
             # near a wave's footprint; behind it the rays of the fine cells a triangle's square
             # touches are looked up (a prefix table over the sorted rays) and tested one by one,
             # and that part -- dependent gathers, not arithmetic -- is what the launch's time is.
             cpl = int(prof.cells_per_lane)
-            c_rows = {2048: 32, 512: 16, 128: 8, 32: 4, 8: 2}[cpl]
-            c_cols = cpl // c_rows
+            # (a wave's footprint is 8 RX columns by 8 RY rows of cells, dealt to its 64 lanes: at least
+            # one column and one row test per lane)
+            c_ry = {2048: 32, 512: 16, 128: 8, 32: 4, 8: 2}[cpl]
+            c_cols, c_rows = max(8 * (cpl // c_ry) // 64, 1), max(8 * c_ry // 64, 1)
             c_instr = (c_cols + c_rows + c_cols // 2 + c_rows // 2 + 2) / cpl
             c_flop = (c_cols + c_rows) / cpl
             c_rate = prof.cell_pairs / (prof.cell_ms * 1e-3) if prof.cell_ms > 0 else 0.0

@@ -445,7 +445,11 @@ constexpr int rt_cells_lane_rows(int r) { return r >= 2048 ? 32 : (r >= 512 ? 16
 constexpr int RT_CELLS_SX = 8, RT_CELLS_SY = 8;     // a wave's 64 lanes are the 8 x 8 phases of the lattice
 constexpr int rt_cells_wave_cols(int r) { return RT_CELLS_SX * (r / rt_cells_lane_rows(r)); }
 constexpr int rt_cells_wave_rows(int r) { return RT_CELLS_SY * rt_cells_lane_rows(r); }
-constexpr int rt_cells_instr(int r) { return r / rt_cells_lane_rows(r) * 3 / 2 + rt_cells_lane_rows(r) * 3 / 2 + 2; }
+// (a footprint's columns and rows are dealt to the 64 lanes: cols / 64 and rows / 64 tests per lane, at least one each)
+constexpr int rt_cells_instr(int r)
+{
+    return ((rt_cells_wave_cols(r) >= 64 ? rt_cells_wave_cols(r) / 64 : 1) + (rt_cells_wave_rows(r) >= 64 ? rt_cells_wave_rows(r) / 64 : 1)) * 3 / 2 + 2;
+}
 // Sorts the listed rays of every set into cells, scales the triangles' squares to each set's
 // grid and fills `plan`; a.S/E/cnt/list/occ_id/tri_order/planes as for rt_launch_sweep_apex,
 // lists = the binned ray numbers (set s at lists + s * a.light_ray_stride, counts_host[s] of them).

@@ -607,13 +607,7 @@ __device__ __forceinline__ void raster_rare_batch(const SweepArgs& A, const floa
     constexpr float COLS = (float)RT_RASTER_COLS;
     int x_lo = 0, nx = 0, r_lo = 0, ny = 0;
     const bool mine = lane < 32 && ((passed >> lane) & 1u);
-    float4 P, M, Hh, N;
     if (mine) {
-        const float4* __restrict__ g4 = A.planes + (tri0 + lane);
-        P = g4[0];
-        M = g4[A.plane_stride];         // (.w: the margin)
-        Hh = g4[2 * A.plane_stride];
-        N = g4[3 * A.plane_stride];
         const float4 box = qbox[lane];
         // columns: pixels px with |(px - W/2) / COLS - cx| <= rx inside the block and the image.  The
         // bounds are rounded inwards to whole pixels: the box was grown by 0.01 pixel and more for
@@ -673,11 +667,14 @@ __device__ __forceinline__ void raster_rare_batch(const SweepArgs& A, const floa
     const int npix = nx * ny;
     unsigned long long todo = __builtin_amdgcn_ballot_w64(npix > 0);
     if (todo == 0) return;
-    if (mine) {
-        qp[lane][0] = P;
-        qp[lane][1] = M;
-        qp[lane][2] = Hh;
-        qp[lane][3] = N;
+    // the planes of the triangles that have pixels here (a part of interleaved row blocks sees every
+    // triangle of the image in its block of rows, and most of them between its rows)
+    if (npix > 0) {
+        const float4* __restrict__ g4 = A.planes + (tri0 + lane);
+        qp[lane][0] = g4[0];
+        qp[lane][1] = g4[A.plane_stride];           // (.w: the margin)
+        qp[lane][2] = g4[2 * A.plane_stride];
+        qp[lane][3] = g4[3 * A.plane_stride];
     }
     // one rectangle after the other, its pixels dealt to the lanes 64 at a time (rectangle and
     // planes are wave-uniform: scalar registers and LDS broadcasts)
