@@ -290,6 +290,7 @@ __device__ __forceinline__ void raster_rare_block(const SweepArgs& A, const floa
         if (in) row_list[ny + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = r;
         ny += __builtin_popcountll(m);
     }
+    wave_lds_sync();
     if (ny == 0) return;
     const float4* __restrict__ g4 = A.planes + tri;
     const float4 P = g4[0], Hh = g4[2 * A.plane_stride], N = g4[3 * A.plane_stride];
@@ -601,7 +602,7 @@ constexpr int kWaveGroup = 2;           // tiles of boxes staged at a time
 template <int NL>
 __device__ __forceinline__ void raster_rare_batch(const SweepArgs& A, const float4* qbox, int tri0, unsigned passed,
                                                   int wave_x0, int wave_y0, const float* rows_y, float4 (*qp)[4],
-                                                  float Xs0, const float (&YL)[NL], int lane)
+                                                  int* flags, float Xs0, const float (&YL)[NL], int lane)
 {
     constexpr int WW = kWaveBlockCols, WH = 64 * NL;
     constexpr float COLS = (float)RT_RASTER_COLS;
@@ -676,24 +677,82 @@ __device__ __forceinline__ void raster_rare_batch(const SweepArgs& A, const floa
         qp[lane][2] = g4[2 * A.plane_stride];
         qp[lane][3] = g4[3 * A.plane_stride];
     }
-    // one rectangle after the other, its pixels dealt to the lanes 64 at a time (rectangle and
-    // planes are wave-uniform: scalar registers and LDS broadcasts)
+    wave_lds_sync();
+    // One rectangle after the other (rectangle and planes are wave-uniform: scalar registers and LDS
+    // broadcasts).  A bounding box is mostly empty -- of the pixels of the million-triangle frame's
+    // rectangles one in eighteen is a candidate -- so the rows of a rectangle are first cut down to
+    // the span the triangle can occupy: U, V, det and W = det - U - V are linear in a pixel's X for a
+    // given row, a hit needs U, V, W >= 0 and det > 0, and the sweep's own allowances say how far the
+    // fp32 values of a true hit can lie below that (by at most delta = margin / 32, and en for det).
+    // The span of a row keeps every X with U, V, W > -margin / 2 and det > -2 en -- four half-lines,
+    // so one interval -- rounded outwards and widened by a pixel on either side; a pixel outside it
+    // cannot be a hit, and the pixels inside it get the inside test of finish_raster as before.
+    // Lane r takes row r of the rectangle (64 rows at a time) and works out its span; then the pixels
+    // of the spans are dealt to the lanes 64 at a time.  A.debug_skip == 4: whole rows (for the tests).
     for (; todo; todo &= todo - 1) {
         const int k = __builtin_ctzll(todo);
         const int knx = __builtin_amdgcn_readlane(nx, k), kx = __builtin_amdgcn_readlane(x_lo, k);
-        const int kr = __builtin_amdgcn_readlane(r_lo, k), kn = __builtin_amdgcn_readlane(npix, k);
+        const int kr = __builtin_amdgcn_readlane(r_lo, k), kny = __builtin_amdgcn_readlane(ny, k);
         const float4 kP = qp[k][0], kH = qp[k][2], kN = qp[k][3];
         const float margin = qp[k][1].w;
-        const float inv = __builtin_amdgcn_rcpf((float)knx);
-        for (int q = lane; q < kn; q += 64) {
-            // q = r knx + c: the quotient from a reciprocal, put right by one where it is off
-            int r = (int)(((float)q + 0.5f) * inv);
-            int c = q - r * knx;
-            if (c < 0) { --r; c += knx; }
-            else if (c >= knx) { ++r; c -= knx; }
-            const int row = kr + r, px = kx + c;
-            finish_raster(A, (long)(wave_y0 + row) * A.W + px, tri0 + k, kP, margin, kH, kN,
-                          (float)(px - A.W / 2) * (1.0f / COLS), rows_y[row]);
+        if (A.debug_skip == 2) continue;
+        const float half_w = (float)(A.W / 2);
+        for (int r0 = 0; r0 < kny; r0 += 64) {
+            const int r = r0 + lane;
+            int c_lo = kx, n_r = 0;
+            if (r < kny) {
+                int c_hi = kx + knx - 1;
+                if (margin != INF && A.debug_skip != 4) {       // (INF: no fp32 verdict, every pixel of the box is listed)
+                    const float Y = rows_y[kr + r];
+                    // f(Xs) = g Xs + c for U, V, det and W (Xs = X / COLS as in finish_raster)
+                    const float gU = -kP.x, cU = -__builtin_fmaf(Y, kP.y, kP.z) - kP.w;
+                    const float gV = COLS * kH.x, cV = __builtin_fmaf(Y, kH.y, kH.z);
+                    const float gD = COLS * kN.x, cD = __builtin_fmaf(Y, kN.y, kN.z);
+                    const float gW = gD - gU - gV, cW = cD - cU - cV;
+                    float lo = -INF, hi = INF;
+                    bool none = false;
+                    auto keep = [&](float g, float c, float least) {     // the X with g X + c > least
+                        const float bound = (least - c) / g;
+                        if (g > 0.0f) lo = __builtin_fmaxf(lo, bound);
+                        else if (g < 0.0f) hi = __builtin_fminf(hi, bound);
+                        else if (!(c > least)) none = true;
+                    };
+                    const float least = -0.5f * margin;
+                    keep(gU, cU, least);
+                    keep(gV, cV, least);
+                    keep(gW, cW, least);
+                    keep(gD, cD, -2.0f * kN.w);
+                    // to pixel columns, outwards, and a pixel more on either side
+                    const float pl = __builtin_fmaf(COLS, lo, half_w), ph = __builtin_fmaf(COLS, hi, half_w);
+                    if (none || !(pl <= ph)) {
+                        c_hi = c_lo - 1;
+                    } else {
+                        if (pl > (float)c_lo) c_lo = (int)__builtin_floorf(pl) - 1 > c_lo ? (int)__builtin_floorf(pl) - 1 : c_lo;
+                        if (ph < (float)c_hi) c_hi = (int)__builtin_ceilf(ph) + 1 < c_hi ? (int)__builtin_ceilf(ph) + 1 : c_hi;
+                    }
+                }
+                n_r = c_hi - c_lo + 1;
+                if (n_r < 0) n_r = 0;
+            }
+            // the pixels of the batch's spans, dealt to the lanes 64 at a time (a running sum over the
+            // rows' span lengths; dealing L lanes to a row, L the power of two that holds the longest
+            // span, was measured: one long span idles most lanes, 2.2 ms against 1.6)
+            const int incl = wave_scan(n_r, lane);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            const int excl = incl - n_r;
+            const int base = c_lo - excl;                   // pixel p of the row's span is column base + p
+            int carry = -1;
+            for (int p0 = 0; p0 < total; p0 += 64) {
+                const int p = p0 + lane;
+                const int q = wave_owner(excl, n_r, p0, flags, carry, lane);     // the row whose span holds pixel p
+                carry = __builtin_amdgcn_readlane(q, 63);
+                const int px = __shfl(base, q) + p;
+                if (p < total) {
+                    const int row = kr + r0 + q;
+                    finish_raster(A, (long)(wave_y0 + row) * A.W + px, tri0 + k, kP, margin, kH, kN,
+                                  (float)(px - A.W / 2) * (1.0f / COLS), rows_y[row]);
+                }
+            }
         }
     }
 }
@@ -709,6 +768,7 @@ k_sweep_raster_wave(const SweepArgs A)
     auto tile = reinterpret_cast<float4 (*)[kWaveGroup * RT_TILE]>(tile_lds);
     __shared__ float row_y[WH];                                 // driver.c:132 per local row of the block, NaN beyond the band
     __shared__ float4 plane_lds[RT_WG / 64][RT_TILE / 4][4];    // the rare path's planes of a quarter tile, per wave
+    __shared__ int owner_lds[RT_WG / 64][64];                   // ... and its scratch for dealing pixels to lanes
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -785,7 +845,7 @@ k_sweep_raster_wave(const SweepArgs A)
                 box_at += 16u * kRasterUnroll;
             }
             if (__builtin_expect(passed != 0 && A.debug_skip != 1, 0))
-                raster_rare_batch<NL>(A, qbox, tri0, passed, wave_x0, wave_y0, row_y, plane_lds[wave], Xs0, YL, lane);
+                raster_rare_batch<NL>(A, qbox, tri0, passed, wave_x0, wave_y0, row_y, plane_lds[wave], owner_lds[wave], Xs0, YL, lane);
         }
         tiles_done += count;
         __builtin_amdgcn_s_waitcnt(0);

@@ -114,7 +114,7 @@ __device__ __forceinline__ bool finish_cell(const CellArgs& A, const CellCtx& X,
 template <int R>
 __device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, const float4* qbox, int tri0,
                                            unsigned passed, int fx0, int fy0, float su, float sv, int lane,
-                                           float4 (*qplanes)[3], unsigned& tested, unsigned& visited)
+                                           float4 (*qplanes)[3], int* flags, unsigned& tested, unsigned& visited)
 {
     using L = CellLane<R>;
     // lane k: the rectangle of triangle k (no rows when the triangle did not pass, or the box
@@ -165,12 +165,15 @@ __device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, 
         qplanes[lane][1] = make_float4(ax == 0 ? Hh.y : Hh.x, ax == 2 ? Hh.y : Hh.z, ax == 0 ? Hh.x : (ax == 1 ? Hh.y : Hh.z), Hh.w);
         qplanes[lane][2] = make_float4(ax == 0 ? N.y : N.x, ax == 2 ? N.y : N.z, ax == 0 ? N.x : (ax == 1 ? N.y : N.z), N.w);
     }
+    wave_lds_sync();
     const int* __restrict__ table = A.table + ((long)X.cell_base << (2 * fl));
     const float qnan = __builtin_nanf("");
+    int carry_e = -1;
     for (int p0 = 0; p0 < rows_total; p0 += 64) {
         // this lane's (triangle, row) pair
         const int p = p0 + lane;
-        const int e = wave_search(rows_incl, p);
+        const int e = wave_owner(rows_excl, ny, p0, flags, carry_e, lane);
+        carry_e = __builtin_amdgcn_readlane(e, 63);
         const int j = p - __shfl(rows_excl, e);
         const int ex = __shfl(x_lo, e), enx = __shfl(nx, e), ey = __shfl(y_lo, e);
         int first = 0, n = 0;
@@ -184,10 +187,12 @@ __device__ __forceinline__ void cells_rare(const CellArgs& A, const CellCtx& X, 
         const int rays_total = A.debug_skip == 2 ? 0 : __builtin_amdgcn_readlane(rays_incl, 63);
         const int rays_excl = rays_incl - n;
         // the ray of lane `lane` in the batch from r0 on: its number and its pair's triangle
-        auto deal = [&](int r0, int& i, int& k) {
-            const int r = r0 + lane;
-            const int q = wave_search(rays_incl, r);        // the pair whose run holds ray r
-            i = __shfl(first, q) + (r - __shfl(rays_excl, q));
+        const int ray_base = first - rays_excl;             // ray r of the batch is ray ray_base + r of its pair's array
+        int carry_q = -1;
+        auto deal = [&](int r0, int& i, int& k) {           // (called for r0 = 0, 64, 128, ... in turn)
+            const int q = wave_owner(rays_excl, n, r0, flags, carry_q, lane);     // the pair whose run holds ray r0 + lane
+            carry_q = __builtin_amdgcn_readlane(q, 63);
+            i = __shfl(ray_base, q) + r0 + lane;
             k = __shfl(e, q);
         };
         // (the next batch's rays are fetched while this batch is tested)
@@ -278,6 +283,7 @@ k_sweep_cells(const CellArgs A)
     __shared__ float4 tile_lds[2 * kGroup * RT_TILE + 1];
     auto tile = reinterpret_cast<float4 (*)[kGroup * RT_TILE]>(tile_lds);
     __shared__ float4 plane_lds[RT_WG / 64][RT_TILE / 4][3];       // the rare path's planes of a quarter tile, per wave
+    __shared__ int owner_lds[RT_WG / 64][64];                      // ... and its scratch for dealing rows and rays to lanes
     using L = CellLane<R>;
 
     const int tid = threadIdx.x;
@@ -351,7 +357,7 @@ k_sweep_cells(const CellArgs A)
             }
             if (__builtin_expect(passed != 0, 0)) {
                 entered += __builtin_popcount(passed);
-                if (A.debug_skip != 1) cells_rare<R>(A, X, qbox, tri0, passed, fx0, fy0, su, sv, lane, plane_lds[wave], tested, visited);
+                if (A.debug_skip != 1) cells_rare<R>(A, X, qbox, tri0, passed, fx0, fy0, su, sv, lane, plane_lds[wave], owner_lds[wave], tested, visited);
             }
         }
         __builtin_amdgcn_s_waitcnt(0);

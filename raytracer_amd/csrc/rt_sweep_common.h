@@ -162,27 +162,65 @@ __device__ __forceinline__ bool candidate_shared(int32_t* __restrict__ cnt_slot,
     return false;
 }
 
+// Inclusive scans over the wave's 64 lanes with data-parallel-primitive moves (no LDS traffic):
+// shifts by 1, 2, 4, 8 lanes inside every row of 16, then the last lane of rows 0 and 2 broadcast
+// into rows 1 and 3, then lane 31 into the upper half.  A lane without a source keeps `identity`.
+#define RT_DPP_SCAN(v, identity, OP)                                                                  \
+    do {                                                                                              \
+        v = OP(v, __builtin_amdgcn_update_dpp((identity), v, 0x111, 0xf, 0xf, false)); /* row_shr:1 */ \
+        v = OP(v, __builtin_amdgcn_update_dpp((identity), v, 0x112, 0xf, 0xf, false)); /* row_shr:2 */ \
+        v = OP(v, __builtin_amdgcn_update_dpp((identity), v, 0x114, 0xf, 0xf, false)); /* row_shr:4 */ \
+        v = OP(v, __builtin_amdgcn_update_dpp((identity), v, 0x118, 0xf, 0xf, false)); /* row_shr:8 */ \
+        v = OP(v, __builtin_amdgcn_update_dpp((identity), v, 0x142, 0xa, 0xf, false)); /* row_bcast:15 */ \
+        v = OP(v, __builtin_amdgcn_update_dpp((identity), v, 0x143, 0xc, 0xf, false)); /* row_bcast:31 */ \
+    } while (0)
+__device__ __forceinline__ int rt_op_add(int a, int b) { return a + b; }
+__device__ __forceinline__ int rt_op_max(int a, int b) { return a > b ? a : b; }
+
 // Running sum over the wave's 64 lanes (inclusive).
 __device__ __forceinline__ int wave_scan(int v, int lane)
 {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(v, off);
-        v += lane >= off ? t : 0;
-    }
+    (void)lane;
+    RT_DPP_SCAN(v, 0, rt_op_add);
     return v;
 }
 
-// The first lane whose running sum `incl` exceeds r (63 when none does).
-__device__ __forceinline__ int wave_search(int incl, int r)
+// Running maximum over the wave's 64 lanes (inclusive).
+__device__ __forceinline__ int wave_scan_max(int v)
 {
-    int l = 0;
-#pragma unroll
-    for (int step = 32; step > 0; step >>= 1) {
-        const int v = __shfl(incl, l + step - 1);
-        l += v <= r ? step : 0;
-    }
-    return l > 63 ? 63 : l;
+    RT_DPP_SCAN(v, (int)0x80000000, rt_op_max);
+    return v;
+}
+
+// Between a lane's LDS stores and other lanes' loads of them within one wave: no barrier is needed
+// in hardware (a wave's LDS accesses complete in program order), but the compiler has to be told
+// that the stores are for other lanes and the loads may see theirs.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Dealing items to lanes.  Lane q owns n_q consecutive items, the first one numbered excl_q (the
+// running sum of the n before it).  For the window of 64 items from p0 on, returns to every lane
+// the lane that owns item p0 + lane: every owner whose first item lies in the window leaves its
+// number at that item's place (LDS, 64 ints of the wave's own), and a running maximum carries it
+// over the items behind (owners ascend with the items).  carry: the owner of item p0 - 1 (-1 for
+// the first window), which owns the window's first items if no run starts there; wave-uniform.
+// An item beyond the last one gets the last owner.
+// (The lanes exchange values through LDS without a barrier -- a wave's LDS accesses complete in
+// program order -- so the accesses are volatile and fenced at wave scope: to the compiler a lane's
+// own store and load would otherwise be all there is.)
+__device__ __forceinline__ int wave_owner(int excl, int n, int p0, int* flags_, int carry, int lane)
+{
+    volatile int* flags = flags_;
+    flags[lane] = -1;
+    const int at = excl - p0;
+    if (n > 0 && at >= 0 && at < 64) flags[at] = lane;
+    wave_lds_sync();
+    const int f = wave_scan_max(flags[lane]);
+    return f > carry ? f : carry;
 }
 
 }  // namespace rt_sweep
