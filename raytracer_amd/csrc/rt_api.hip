@@ -501,8 +501,9 @@ static int transform_into(rt_scene* sc, const double m[4][4], bool bake)
                                      sc->oz.as<double>(), sc->ex.as<double>(), sc->ey.as<double>(),
                                      sc->ez.as<double>(), n, sc->scratch_max.as<unsigned>(), st);
             if (rc) break;
-            rc = rt_launch_pack(sc, st);
+            rc = rt_launch_pack(sc, st, false, true);
             if (rc) break;
+            sc->planes_ready = false;
             sc->transformed = true;
         }
         float radius = 0;
@@ -1026,6 +1027,10 @@ static int trace_rays_impl(rt_scene* sc, const RayWorkspace* static_ws, int n, c
     if (!static_ws) RT_TRY(workspaces(sc, (size_t)n));
     const RayWorkspace ws = static_ws ? *static_ws : scene_workspace(sc);
     RT_HIP(hipMemsetAsync(ws.counters, 0, 64, st));
+    if (!sc->planes_ready) {        // first rays in general position since the transform
+        RT_TRY(rt_launch_pack(sc, st, true, false));
+        sc->planes_ready = true;
+    }
     SweepArgs a{};
     a.planes = sc->planes.as<float4>(); a.plane_stride = sc->num_tris_padded;
     a.num_tris = sc->num_tris; a.num_tris_padded = sc->num_tris_padded;

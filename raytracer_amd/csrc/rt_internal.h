@@ -170,6 +170,7 @@ struct rt_scene {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf tri_verts;           // 9 doubles per triangle, eye space (see ExactScene::tv)
+    bool planes_ready = false;  // the general sweep's planes hold the current transform
     DevBuf scratch_max;         // 1 float: max |coordinate| of the eye-space vertices
     DevBuf mat_dev;             // the 4x4 of the current transform
 
@@ -227,7 +228,10 @@ int rt_device_cus();        // compute units of the device (cached; every device
 // rt_transform.hip
 int rt_launch_transform(const double* m16, const double* x, const double* y, const double* z,
                         double* X, double* Y, double* Z, int n, unsigned* max_bits, hipStream_t st);
-int rt_launch_pack(rt_scene* sc, hipStream_t st);
+// planes: the general sweep's planes (rt_sweep.hip); verts: the exact pass's copy of the triangles.
+// A transform writes the copy only; the planes follow when rays in general position are traced
+// (rt_scene::planes_ready).
+int rt_launch_pack(rt_scene* sc, hipStream_t st, bool planes, bool verts);
 // apex planes for rays through `apex`; zs is folded into the z components (the constant z of
 // pixel-grid directions, 1 otherwise); dmax bounds |D| of every ray of the sweep
 // squares (or nullptr): three more planes of num_tris_padded entries, the bounding squares of the

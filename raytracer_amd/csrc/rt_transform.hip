@@ -62,26 +62,30 @@ k_pack(const double* __restrict__ x, const double* __restrict__ y, const double*
        int num_tris, int num_tris_padded, const unsigned* __restrict__ max_bits,
        float4* __restrict__ planes, double* __restrict__ tri_verts)
 {
+    // planes (or nullptr): the general sweep's planes; tri_verts (or nullptr): the exact pass's copy
     const int i = blockIdx.x * RT_WG + threadIdx.x;
     if (i >= num_tris_padded) return;
     float4* p[RT_PLANES];
 #pragma unroll
     for (int k = 0; k < RT_PLANES; ++k) p[k] = planes + (long)k * num_tris_padded + i;
     if (i >= num_tris) {        // padding: a null triangle can never pass the filter
+        if (planes) {
 #pragma unroll
-        for (int k = 0; k < RT_PLANES; ++k) *p[k] = make_float4(0, 0, 0, 0);
+            for (int k = 0; k < RT_PLANES; ++k) *p[k] = make_float4(0, 0, 0, 0);
+        }
         return;
     }
     const int a = iA[i], b = iB[i], c = iC[i];
     const double ax = x[a], ay = y[a], az = z[a];
     const double bx = x[b], by = y[b], bz = z[b];
     const double cx = x[c], cy = y[c], cz = z[c];
-    {       // the exact pass's copy of the triangle
+    if (tri_verts) {       // the exact pass's copy of the triangle
         double* t = tri_verts + 9 * (long)i;
         t[0] = ax; t[1] = ay; t[2] = az;
         t[3] = bx; t[4] = by; t[5] = bz;
         t[6] = cx; t[7] = cy; t[8] = cz;
     }
+    if (!planes) return;
     const double e1x = bx - ax, e1y = by - ay, e1z = bz - az;
     const double e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
     const double l1 = sqrt(e1x * e1x + e1y * e1y + e1z * e1z);
@@ -133,7 +137,8 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
             const int* __restrict__ iA, const int* __restrict__ iB, const int* __restrict__ iC,
             int num_tris, int num_tris_padded, const unsigned* __restrict__ max_bits,
             double px, double py, double pz, double zs, double dmax, int sign_layout,
-            const int32_t* __restrict__ order, float4* __restrict__ planes, float4* __restrict__ squares)
+            const int32_t* __restrict__ order, const double* __restrict__ tri_verts,
+            float4* __restrict__ planes, float4* __restrict__ squares)
 {
     const int i = blockIdx.x * RT_WG + threadIdx.x;      // entry of the plane arrays
     if (i >= num_tris_padded) return;
@@ -145,10 +150,20 @@ k_pack_apex(const double* __restrict__ x, const double* __restrict__ y, const do
     bool null_tri = src < 0 || src >= num_tris;
     double a0x = 0, a0y = 0, a0z = 0, a1x = 0, a1y = 0, a1z = 0, a2x = 0, a2y = 0, a2z = 0;
     if (!null_tri) {
-        const int a = iA[src], b = iB[src], c = iC[src];
-        a0x = x[a] - px; a0y = y[a] - py; a0z = z[a] - pz;
-        a1x = x[b] - px; a1y = y[b] - py; a1z = z[b] - pz;
-        a2x = x[c] - px; a2y = y[c] - py; a2z = z[c] - pz;
+        if (tri_verts) {
+            // the triangle's vertices from the copy k_pack keeps for the exact pass: 72 bytes in one
+            // place (with a scattered order, three indices and nine coordinates fetched through
+            // them are twelve cache lines)
+            const double* t = tri_verts + 9 * (long)src;
+            a0x = t[0] - px; a0y = t[1] - py; a0z = t[2] - pz;
+            a1x = t[3] - px; a1y = t[4] - py; a1z = t[5] - pz;
+            a2x = t[6] - px; a2y = t[7] - py; a2z = t[8] - pz;
+        } else {
+            const int a = iA[src], b = iB[src], c = iC[src];
+            a0x = x[a] - px; a0y = y[a] - py; a0z = z[a] - pz;
+            a1x = x[b] - px; a1y = y[b] - py; a1z = z[b] - pz;
+            a2x = x[c] - px; a2y = y[c] - py; a2z = z[c] - pz;
+        }
 #if RT_PACK_ROTATE
         // The sweep's first test is the u slab: the strip between the line through a0 and a2 and
         // its parallel through a1.  Which vertex is called a0 does not matter to the filter
@@ -369,7 +384,7 @@ int rt_launch_pack_apex(rt_scene* sc, const double apex[3], double zs, double dm
                        sc->ex.as<double>(), sc->ey.as<double>(), sc->ez.as<double>(),
                        sc->iA.as<int>(), sc->iB.as<int>(), sc->iC.as<int>(), sc->num_tris, np,
                        sc->scratch_max.as<unsigned>(), apex[0], apex[1], apex[2], zs, dmax,
-                       sign_layout ? 1 : 0, order, dst, squares);
+                       sign_layout ? 1 : 0, order, sc->transformed ? sc->tri_verts.as<double>() : nullptr, dst, squares);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("apex pack launch failed: %s", hipGetErrorString(e));
@@ -393,13 +408,14 @@ int rt_launch_transform(const double* m16, const double* x, const double* y, con
     return RT_OK;
 }
 
-int rt_launch_pack(rt_scene* sc, hipStream_t st)
+int rt_launch_pack(rt_scene* sc, hipStream_t st, bool planes, bool verts)
 {
     const int np = sc->num_tris_padded;
     hipLaunchKernelGGL(k_pack, dim3((np + RT_WG - 1) / RT_WG), dim3(RT_WG), 0, st,
                        sc->ex.as<double>(), sc->ey.as<double>(), sc->ez.as<double>(),
                        sc->iA.as<int>(), sc->iB.as<int>(), sc->iC.as<int>(), sc->num_tris, np,
-                       sc->scratch_max.as<unsigned>(), sc->planes.as<float4>(), sc->tri_verts.as<double>());
+                       sc->scratch_max.as<unsigned>(), planes ? sc->planes.as<float4>() : nullptr,
+                       verts ? sc->tri_verts.as<double>() : nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("pack launch failed: %s", hipGetErrorString(e));
