@@ -232,7 +232,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
     }
     DevBuf* bufs[] = {&sc->ox, &sc->oy, &sc->oz, &sc->ex, &sc->ey, &sc->ez, &sc->nx, &sc->ny, &sc->nz,
                       &sc->tu, &sc->tv, &sc->iA, &sc->iB, &sc->iC, &sc->iAn, &sc->iBn, &sc->iCn,
-                      &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts,
+                      &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts, &sc->tri_normals,
                       &sc->scratch_max, &sc->mat_dev, &sc->ws_partials, &sc->ws_frame, &sc->planes_light, &sc->ws_sort_tri, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi, &sc->ws_axis,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
                       &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort, &sc->tri_order, &sc->tri_scatter,
@@ -274,6 +274,7 @@ extern "C" int rt_scene_set_normals(rt_scene* sc, int num_vn, const double* xn, 
     RT_TRY(upload(sc->ny, yn, bytes));
     RT_TRY(upload(sc->nz, zn, bytes));
     sc->num_vn = num_vn;
+    sc->tri_normals_ready = false;
     return RT_OK;
 }
 
@@ -357,6 +358,7 @@ extern "C" int rt_scene_set_triangles(rt_scene* sc, int num_tris, const int* A, 
     RT_TRY(sc->tri_verts.reserve(sizeof(double) * 9 * (size_t)(num_tris > 0 ? num_tris : 1)));
     RT_TRY(sc->scratch_max.reserve(16));
     sc->tri_scatter_ready = false;
+    sc->tri_normals_ready = false;
     sc->transformed = false;
     return RT_OK;
 }
@@ -1341,6 +1343,12 @@ static int render_rows_impl(rt_scene* sc, const rt_frame* f, int W, int H, doubl
     a.Ct = sc->has_tex_idx ? sc->iCt.as<int>() : nullptr;
     a.mtl = sc->imtl.p ? sc->imtl.as<int>() : nullptr;
     a.nx = sc->nx.as<double>(); a.ny = sc->ny.as<double>(); a.nz = sc->nz.as<double>();
+    if (!sc->tri_normals_ready) {       // once per mesh: the normals do not move with the transform
+        RT_TRY(sc->tri_normals.reserve(sizeof(double) * 9 * (size_t)(sc->num_tris > 0 ? sc->num_tris : 1)));
+        RT_TRY(rt_launch_pack_normals(a.nx, a.ny, a.nz, a.An, a.Bn, a.Cn, sc->num_tris, sc->tri_normals.as<double>(), st));
+        sc->tri_normals_ready = true;
+    }
+    a.tn = sc->tri_normals.as<double>();
     a.tu = sc->tu.as<double>(); a.tv = sc->tv.as<double>();
     a.mats = sc->mats.as<DevMaterial>(); a.tex = sc->tex_desc.as<DevTexture>();
     a.num_mats = sc->num_mats;

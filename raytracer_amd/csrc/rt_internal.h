@@ -170,6 +170,8 @@ struct rt_scene {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf tri_verts;           // 9 doubles per triangle, eye space (see ExactScene::tv)
+    DevBuf tri_normals;         // 9 doubles per triangle: its vertex normals, object space (ShadeArgs::tn)
+    bool tri_normals_ready = false;
     bool planes_ready = false;  // the general sweep's planes hold the current transform
     DevBuf scratch_max;         // 1 float: max |coordinate| of the eye-space vertices
     DevBuf mat_dev;             // the 4x4 of the current transform
@@ -506,6 +508,7 @@ struct ShadeArgs {
     ExactScene es;
     const int *An, *Bn, *Cn, *At, *Bt, *Ct, *mtl;
     const double *nx, *ny, *nz, *tu, *tv;
+    const double* tn;         // 9 doubles per triangle: its three vertex normals (or nullptr: through An.. and nx..)
     const DevMaterial* mats;
     const DevTexture* tex;
     int num_mats;
@@ -522,6 +525,8 @@ struct ShadeArgs {
     double* argb;
     uint8_t* rgb8;
 };
+int rt_launch_pack_normals(const double* nx, const double* ny, const double* nz, const int* An, const int* Bn,
+                           const int* Cn, int num_tris, double* out, hipStream_t st);
 int rt_launch_shadow_setup(const ShadeArgs& a, hipStream_t st);
 int rt_launch_shade_final(const ShadeArgs& a, hipStream_t st);
 int rt_launch_place_rows(const uint8_t* rgb8, int W, int H, const RowMap& rows, uint8_t* screen,

@@ -53,10 +53,21 @@ __device__ __forceinline__ void hit_point(const ShadeArgs& a, long p, double poi
 __device__ __forceinline__ void interp_normal(const ShadeArgs& a, int tri, double u, double v,
                                               double normal[3])
 {
-    const int ia = a.An[tri], ib = a.Bn[tri], ic = a.Cn[tri];
-    const double An[3] = {a.nx[ia], a.ny[ia], a.nz[ia]};
-    const double Bn[3] = {a.nx[ib], a.ny[ib], a.nz[ib]};
-    const double Cn[3] = {a.nx[ic], a.ny[ic], a.nz[ic]};
+    double An[3], Bn[3], Cn[3];
+    if (a.tn) {
+        // the three vertex normals from the per-triangle copy (k_pack_normals): neighbouring pixels
+        // of a fine mesh hit different triangles, and three indices with nine coordinates fetched
+        // through them are twelve cache lines a pixel where the copy is two
+        const double* t = a.tn + 9 * (long)tri;
+        An[0] = t[0]; An[1] = t[1]; An[2] = t[2];
+        Bn[0] = t[3]; Bn[1] = t[4]; Bn[2] = t[5];
+        Cn[0] = t[6]; Cn[1] = t[7]; Cn[2] = t[8];
+    } else {
+        const int ia = a.An[tri], ib = a.Bn[tri], ic = a.Cn[tri];
+        An[0] = a.nx[ia]; An[1] = a.ny[ia]; An[2] = a.nz[ia];
+        Bn[0] = a.nx[ib]; Bn[1] = a.ny[ib]; Bn[2] = a.nz[ib];
+        Cn[0] = a.nx[ic]; Cn[1] = a.ny[ic]; Cn[2] = a.nz[ic];
+    }
     double Nt[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) Nt[k] = (1 - u - v) * An[k] + u * Bn[k] + v * Cn[k];
@@ -248,6 +259,21 @@ k_place_rows(const uint8_t* __restrict__ rgb8, int W, int H, RowMap rows,
     screen[(long)(H - y_pix) * W * 3 + col] = rgb8[i];
 }
 
+// The vertex normals of every triangle side by side (object space, as uploaded): 9 doubles.
+__global__ void __launch_bounds__(RT_WG)
+k_pack_normals(const double* __restrict__ nx, const double* __restrict__ ny, const double* __restrict__ nz,
+               const int* __restrict__ An, const int* __restrict__ Bn, const int* __restrict__ Cn, int num_tris,
+               double* __restrict__ out)
+{
+    const int i = blockIdx.x * RT_WG + threadIdx.x;
+    if (i >= num_tris) return;
+    const int ia = An[i], ib = Bn[i], ic = Cn[i];
+    double* t = out + 9 * (long)i;
+    t[0] = nx[ia]; t[1] = ny[ia]; t[2] = nz[ia];
+    t[3] = nx[ib]; t[4] = ny[ib]; t[5] = nz[ib];
+    t[6] = nx[ic]; t[7] = ny[ic]; t[8] = nz[ic];
+}
+
 int launched(const char* what)
 {
     hipError_t e = hipGetLastError();
@@ -259,6 +285,15 @@ int launched(const char* what)
 }
 
 }  // namespace
+
+int rt_launch_pack_normals(const double* nx, const double* ny, const double* nz, const int* An, const int* Bn,
+                           const int* Cn, int num_tris, double* out, hipStream_t st)
+{
+    if (num_tris <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_pack_normals, dim3((unsigned)((num_tris + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0, st, nx, ny,
+                       nz, An, Bn, Cn, num_tris, out);
+    return launched("pack_normals");
+}
 
 int rt_launch_shadow_setup(const ShadeArgs& a, hipStream_t st)
 {
