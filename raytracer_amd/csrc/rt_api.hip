@@ -235,7 +235,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts, &sc->tri_normals,
                       &sc->scratch_max, &sc->mat_dev, &sc->ws_partials, &sc->ws_frame, &sc->planes_light, &sc->ws_sort_tri, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi, &sc->ws_axis,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
-                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_occid, &sc->ws_sort, &sc->tri_order, &sc->tri_scatter,
+                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_bin_pad, &sc->ws_occid, &sc->ws_sort, &sc->tri_order, &sc->tri_scatter,
                       &sc->ws_cell_rays, &sc->ws_cell_table, &sc->ws_cell_boxes, &sc->ws_cell_wide};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : sc->tex_data) b.release();
@@ -997,6 +997,7 @@ static int anyhit_buffers(rt_scene* sc, size_t entries)
     RT_TRY(sc->ws_act0.reserve(sizeof(int32_t) * entries));
     RT_TRY(sc->ws_act1.reserve(sizeof(int32_t) * entries));
     RT_TRY(sc->ws_live.reserve(sizeof(int) * (3 + RT_COMPACT_SLICES) * RT_APEX_SETS));   // counts + the compaction's slice sums
+    RT_TRY(sc->ws_bin_pad.reserve(sizeof(int) * RT_BIN_COUNT_STRIDE * RT_APEX_SETS));
     return RT_OK;
 }
 
@@ -1199,7 +1200,7 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
         };
         RT_HIP(hipMemsetAsync(sc->ws_live.p, 0, sizeof(int) * 3 * RT_APEX_SETS, st));
         if (!use_cache) {
-            RT_TRY(rt_launch_bin_rays(a.S, a.E, ax, hit, W, nrows, lights, (long)npix, 1, 0, act0, live0, st));
+            RT_TRY(rt_launch_bin_rays(a.S, a.E, ax, hit, W, nrows, lights, (long)npix, 1, 0, act0, live0, sc->ws_bin_pad.as<int>(), st));
             RT_TRY(phase());
             continue;
         }
@@ -1216,10 +1217,10 @@ static int trace_shadow_rays(rt_scene* sc, const rt_frame* f, int W, int nrows, 
             a.occ_id = record ? occ_id : nullptr;
             RT_HIP(hipMemsetAsync(live0, 0, sizeof(int) * 3 * RT_APEX_SETS, st));
             if (level == 0) {
-                RT_TRY(rt_launch_bin_rays(a.S, a.E, ax, hit, W, nrows, lights, (long)npix, step, 0, act0, live0, st));
+                RT_TRY(rt_launch_bin_rays(a.S, a.E, ax, hit, W, nrows, lights, (long)npix, step, 0, act0, live0, sc->ws_bin_pad.as<int>(), st));
             } else {
                 const int coarser = RT_SHADOW_STEPS[level - 1];
-                RT_TRY(rt_launch_bin_rays(a.S, a.E, ax, hit, W, nrows, lights, (long)npix, step, coarser, act2, live2, st));
+                RT_TRY(rt_launch_bin_rays(a.S, a.E, ax, hit, W, nrows, lights, (long)npix, step, coarser, act2, live2, sc->ws_bin_pad.as<int>(), st));
                 RT_TRY(rt_launch_try_cached(exact_of(sc), a.S, a.E, act2, live2, sets, (int)npix, (long)npix,
                                             W, nrows, row_block, coarser, record, a.cnt, occ_id, st));
                 RT_TRY(rt_launch_compact(a.cnt, act2, live2, (int)npix, sets, (long)npix, 3, act0, live0,

@@ -118,13 +118,24 @@ __device__ __forceinline__ bool confirm_list(const ExactScene& es, const double 
     ncand = n;
     const int32_t* l = slot_major ? list + p : list + p * K;
     const long step = slot_major ? slot_major : 1;
-    for (int k = 0; k < n; ++k) {
-        const int i = l[k * step];
-        double u, v;
-        const double dist = exact_tri(es, i, S, E, u, v);
-        if ((dist > 0) && (dist < best.t || (dist == best.t && i < best.idx))) {       // :169
-            best.t = dist; best.u = u; best.v = v; best.idx = i;
-            if (ANYHIT) { occluded = true; return true; }
+    // four entries at a time, fetched together whether the list has them or not (all K slots
+    // exist): fetched one by one as they were tested, every candidate cost a memory round trip for
+    // its number before the one for its vertices
+    static_assert(K % 4 == 0, "the list is read in groups of four slots");
+    for (int k0 = 0; k0 < n; k0 += 4) {
+        int ids[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ids[j] = l[(k0 + j) * step];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (k0 + j >= n) break;
+            const int i = ids[j];
+            double u, v;
+            const double dist = exact_tri(es, i, S, E, u, v);
+            if ((dist > 0) && (dist < best.t || (dist == best.t && i < best.idx))) {       // :169
+                best.t = dist; best.u = u; best.v = v; best.idx = i;
+                if (ANYHIT) { occluded = true; return true; }
+            }
         }
     }
     return true;

@@ -183,7 +183,7 @@ struct rt_scene {
 
     // per-call workspaces (grow-only)
     DevBuf ws_cnt, ws_list, ws_ovf, ws_counters, ws_besthi, ws_partials, ws_frame, ws_axis;
-    DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_act2, ws_live, ws_occid, ws_sort;
+    DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_act2, ws_live, ws_bin_pad, ws_occid, ws_sort;
     // the cell-lattice any-hit sweep (rt_sweep_cells.hip): sort space and ray records, the cell
     // table, the triangles' boxes in cell units
     DevBuf ws_cell_rays, ws_cell_table, ws_cell_boxes, ws_cell_wide;
@@ -373,8 +373,12 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st);     // any-hit ove
 // multiples of step_out (0: no exclusion): the levels of the occluder cache.
 // hit (or nullptr): the primary hit of every local pixel; pixels that hit nothing have no rays and
 // their slots in S and E are not read
+// padded_counts: RT_BIN_COUNT_STRIDE * RT_APEX_SETS ints of scratch (the launch counts there, one
+// counter per 256 bytes, and copies the totals to out_counts, which it overwrites)
+constexpr int RT_BIN_COUNT_STRIDE = 64;
 int rt_launch_bin_rays(const double* S, const double* E, const int8_t* axis, const int32_t* hit, int W, int rows, int lights,
-                       long stride, int step_in, int step_out, int32_t* out, int* out_counts, hipStream_t st);
+                       long stride, int step_in, int step_out, int32_t* out, int* out_counts, int* padded_counts,
+                       hipStream_t st);
 // Pixel spacing of the occluder cache's levels, coarsest first; the last must be 1.  (A third,
 // coarser level -- 16, 4, 1 -- was measured: it saves 4 % of the pair tests and loses more than
 // that to its extra chain of small launches.)

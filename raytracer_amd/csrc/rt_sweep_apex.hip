@@ -1287,93 +1287,129 @@ k_sweep_apex(SweepArgs A)
 
 // Bins the shadow rays of every light by the dominant axis of their direction: ray numbers
 // (local pixel numbers) of set light * 3 + axis go to out[set * stride ...], their number to
-// out_counts[set].  Rays are visited in the order of the 64 x 16 pixel tiles, and every
-// workgroup writes its slice in that order, so the rays of a sweep workgroup stay neighbours on
-// the screen (they tend to retire together).  Unused slots (NaN origin) are left out, and
-// step_in / step_out select the rays of one level of the occluder cache.
+// out_counts[set].  Rays are visited in the order of tiles of 64 x 16 pixels of the step_in grid, and
+// every workgroup writes its slice in that order, so the rays of a sweep workgroup stay
+// neighbours on the screen (they tend to retire together).  Unused slots (NaN origin) are left
+// out, and step_in / step_out select the rays of one level of the occluder cache.
+// A workgroup takes kBinRounds x RT_WG consecutive entries of that order, a lane one of every
+// round: all its look-ups are in flight together, one pass, two barriers (a pass to count and a
+// pass to place, each round waiting for its own loads and two barriers, took 100-130 us for a
+// 3840 x 2160 frame where the bytes moved are worth 20).
+constexpr int kBinRounds = 16;
+// The workgroups of a launch all add to the same few counters.  Counters that share a cache line
+// are served one after the other, whichever of them an update is for: thousands of workgroups
+// times three sets of a light in one line took 80 us of a launch whose data is worth 20.  So
+// k_bin_rays counts into a scratch array with one counter per 256 bytes, and k_bin_counts copies
+// the totals to where everything else reads them.
+constexpr int kBinCountStride = RT_BIN_COUNT_STRIDE;
+__global__ void k_bin_counts(const int* __restrict__ padded, int sets, int* __restrict__ out_counts)
+{
+    if ((int)threadIdx.x < sets) out_counts[threadIdx.x] = padded[threadIdx.x * kBinCountStride];
+}
+
 __global__ void __launch_bounds__(RT_WG)
 k_bin_rays(const double* __restrict__ S, const double* __restrict__ E, const int8_t* __restrict__ axis,
            const int32_t* __restrict__ hit, int W, int rows, long stride, int step_in, int step_out,
            int32_t* __restrict__ out, int* __restrict__ out_counts)
 {
-    __shared__ int s_wave[RT_WG / 64][3];
+    constexpr int WAVES = RT_WG / 64;
+    static_assert(kBinRounds * WAVES == 64, "one wave scans the (round, wave) counts");
+    __shared__ int s_cnt[3][kBinRounds * WAVES];
     __shared__ int s_base[3];
     const long light = blockIdx.y;
     S += 3 * light * stride;
     E += 3 * light * stride;
     if (axis) axis += light * stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles_x = (W + 63) / 64, tiles_y = (rows + 15) / 16;
+    // the entries: the pixels of the step_in grid (one level of the occluder cache), in tiles of
+    // 64 x 16 of them
+    const int Ws = (W + step_in - 1) / step_in, Rs = (rows + step_in - 1) / step_in;
+    const int tiles_x = (Ws + 63) / 64, tiles_y = (Rs + 15) / 16;
     const long total = (long)tiles_x * tiles_y * 1024;
-    const long per = ((total + gridDim.x - 1) / gridDim.x + RT_WG - 1) / RT_WG * RT_WG;
-    const long lo = per * blockIdx.x, hi = lo + per < total ? lo + per : total;
-    if (lo >= total) return;
-    auto classify = [&](long e, int& id) {          // -1 = no ray, else dominant axis
-        id = -1;
-        if (e >= hi) return -1;
-        const long t = e >> 10;
-        const int w = (int)(e & 1023), tx = (int)(t % tiles_x), ty = (int)(t / tiles_x);
-        const int px = tx * 64 + (w & 63), lr = ty * 16 + (w >> 6);
-        if (px >= W || lr >= rows) return -1;
-        // one level of the occluder cache: on the step_in grid, not on the coarser step_out grid
-        if (px % step_in != 0 || lr % step_in != 0) return -1;
-        if (step_out > 0 && px % step_out == 0 && lr % step_out == 0) return -1;
-        id = lr * W + px;
-        if (hit && hit[id] < 0) return -1;          // the pixel hit nothing: its ray slots were never written
-        if (axis) return (int)axis[id];             // (the same classification, made when the ray was)
-        const double* s = S + 3 * (long)id;
-        const double* en = E + 3 * (long)id;
-        const double sx = s[0];
-        if (!(sx == sx)) return -1;                 // unused slot
-        const double dx = fabs(en[0] - sx), dy = fabs(en[1] - s[1]), dz = fabs(en[2] - s[2]);
-        if (!(dx + dy + dz > 0) || !(dx + dy + dz < 1e300)) return -1;     // zero-length or non-finite: hits nothing
-        return dx >= dy && dx >= dz ? 0 : (dy >= dz ? 1 : 2);
-    };
-    int mine[3] = {0, 0, 0};
-    for (long e = lo + threadIdx.x; e - threadIdx.x < hi; e += RT_WG) {
-        int id;
-        const int ax = classify(e, id);
+    const long lo = (long)blockIdx.x * (kBinRounds * RT_WG);
+    int id[kBinRounds], ax[kBinRounds];
+    // (no division per entry: a workgroup's entries are kBinRounds / 4 whole tiles, and the sample
+    // steps are powers of two in practice)
+    static_assert(RT_WG == 256 && kBinRounds % 4 == 0, "a tile is four rounds");
+    const int out_mask = step_out > 0 && (step_out & (step_out - 1)) == 0 ? step_out - 1 : -1;
+    auto on_grid = [](int v, int step, int mask) { return mask >= 0 ? (v & mask) == 0 : v % step == 0; };
+    const long t0 = lo >> 10;
+    int tx = (int)(t0 % tiles_x), ty = (int)(t0 / tiles_x);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) mine[k] += ax == k;
+    for (int r = 0; r < kBinRounds; ++r) {
+        const int w = (r & 3) * RT_WG + (int)threadIdx.x;
+        const int px = step_in * (tx * 64 + (w & 63)), lr = step_in * (ty * 16 + (w >> 6));
+        bool ok = lo + (long)r * RT_WG + threadIdx.x < total && px < W && lr < rows;
+        // ... and not on the coarser step_out grid, whose rays went before
+        ok = ok && !(step_out > 0 && on_grid(px, step_out, out_mask) && on_grid(lr, step_out, out_mask));
+        id[r] = ok ? lr * W + px : -1;
+        if ((r & 3) == 3 && ++tx == tiles_x) { tx = 0; ++ty; }
     }
+    if (axis) {
+        // (the classification made when the ray was written; a pixel that hit nothing has no ray
+        // and its slots were never written: hit[] decides)
+        // (unconditional loads, entry 0 standing in where there is no pixel: a load under a
+        // condition is waited for inside its branch, sixteen round trips one after the other)
+        int h[kBinRounds];
+        if (hit) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+            for (int r = 0; r < kBinRounds; ++r) h[r] = hit[id[r] < 0 ? 0 : id[r]];
+        } else {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mine[k] += __shfl_xor(mine[k], off);
-        if (lane == 0) s_wave[wave][k] = mine[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        int total_k = 0;
-        for (int wv = 0; wv < RT_WG / 64; ++wv) total_k += s_wave[wv][threadIdx.x];
-        s_base[threadIdx.x] = total_k ? atomicAdd(&out_counts[light * 3 + threadIdx.x], total_k) : 0;
-    }
-    __syncthreads();
-    int base[3] = {s_base[0], s_base[1], s_base[2]};
-    for (long e = lo + threadIdx.x; e - threadIdx.x < hi; e += RT_WG) {
-        int id;
-        const int ax = classify(e, id);
-        unsigned long long m[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) m[k] = __ballot(ax == k);
-        __syncthreads();                 // s_wave is reused every round
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) s_wave[wave][k] = __popcll(m[k]);
+            for (int r = 0; r < kBinRounds; ++r) h[r] = 0;
         }
-        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kBinRounds; ++r) ax[r] = (int)axis[id[r] < 0 ? 0 : id[r]];
+#pragma unroll
+        for (int r = 0; r < kBinRounds; ++r) ax[r] = (id[r] < 0 || h[r] < 0) ? -1 : ax[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < kBinRounds; ++r) {
+            ax[r] = -1;
+            if (id[r] < 0 || (hit && hit[id[r]] < 0)) continue;
+            const double* s = S + 3 * (long)id[r];
+            const double* en = E + 3 * (long)id[r];
+            const double sx = s[0];
+            if (!(sx == sx)) continue;                  // unused slot
+            const double dx = fabs(en[0] - sx), dy = fabs(en[1] - s[1]), dz = fabs(en[2] - s[2]);
+            if (!(dx + dy + dz > 0) || !(dx + dy + dz < 1e300)) continue;      // zero-length or non-finite: hits nothing
+            ax[r] = dx >= dy && dx >= dz ? 0 : (dy >= dz ? 1 : 2);
+        }
+    }
+    // a ray's place: the rays of its set in the rounds and waves before it, then in the lanes before it
+    int before[kBinRounds];
+#pragma unroll
+    for (int r = 0; r < kBinRounds; ++r) {
+        before[r] = 0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            int before = 0, total_k = 0;
-#pragma unroll
-            for (int wv = 0; wv < RT_WG / 64; ++wv) {
-                before += wv < wave ? s_wave[wv][k] : 0;
-                total_k += s_wave[wv][k];
-            }
-            if (ax == k)
-                out[(light * 3 + k) * stride + base[k] + before + __popcll(m[k] & ((1ull << lane) - 1))] = id;
-            base[k] += total_k;
+            const unsigned long long m = __ballot(ax[r] == k);
+            if (lane == 0) s_cnt[k][r * WAVES + wave] = __popcll(m);
+            if (ax[r] == k) before[r] = __popcll(m & ((1ull << lane) - 1));
         }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int total_k[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int c = s_cnt[k][lane];
+            const int incl = rt_sweep::wave_scan(c, lane);
+            total_k[k] = __builtin_amdgcn_readlane(incl, 63);
+            s_cnt[k][lane] = incl - c;
+        }
+        // the three reservations in one instruction (one after the other, each waited for the
+        // counter's answer before the next left)
+        if (lane < 3) {
+            const int t = lane == 0 ? total_k[0] : (lane == 1 ? total_k[1] : total_k[2]);
+            s_base[lane] = t ? atomicAdd(&out_counts[(light * 3 + lane) * kBinCountStride], t) : 0;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kBinRounds; ++r) {
+        const int k = ax[r];
+        if (k >= 0) out[(light * 3 + k) * stride + s_base[k] + s_cnt[k][r * WAVES + wave] + before[r]] = id[r];
     }
 }
 
@@ -1721,18 +1757,28 @@ int rt_launch_sweep_apex(const SweepArgs& a, hipStream_t st)
 }
 
 int rt_launch_bin_rays(const double* S, const double* E, const int8_t* axis, const int32_t* hit, int W, int rows,
-                       int lights, long stride, int step_in, int step_out, int32_t* out, int* out_counts, hipStream_t st)
+                       int lights, long stride, int step_in, int step_out, int32_t* out, int* out_counts,
+                       int* padded_counts, hipStream_t st)
 {
     if (W <= 0 || rows <= 0 || lights <= 0) return RT_OK;
+    if (!padded_counts || lights * 3 > RT_APEX_SETS) {
+        rt_set_error("bin_rays: bad arguments");
+        return RT_E_ARG;
+    }
+    if (hipMemsetAsync(padded_counts, 0, sizeof(int) * RT_BIN_COUNT_STRIDE * RT_APEX_SETS, st) != hipSuccess) {
+        rt_set_error("bin_rays: clearing the counters failed");
+        return RT_E_HIP;
+    }
     if (step_in < 1 || step_out < 0) {
         rt_set_error("bin_rays: bad sample steps");
         return RT_E_ARG;
     }
-    const long total = (long)((W + 63) / 64) * ((rows + 15) / 16) * 1024;
-    long wgs = (total + RT_WG - 1) / RT_WG;
-    if (wgs > 2048) wgs = 2048;
+    const int Ws = (W + step_in - 1) / step_in, Rs = (rows + step_in - 1) / step_in;
+    const long total = (long)((Ws + 63) / 64) * ((Rs + 15) / 16) * 1024;
+    const long wgs = (total + (long)kBinRounds * RT_WG - 1) / ((long)kBinRounds * RT_WG);
     hipLaunchKernelGGL(k_bin_rays, dim3((unsigned)wgs, lights), dim3(RT_WG), 0, st, S, E, axis, hit, W, rows,
-                       stride, step_in, step_out, out, out_counts);
+                       stride, step_in, step_out, out, padded_counts);
+    hipLaunchKernelGGL(k_bin_counts, dim3(1), dim3(64), 0, st, padded_counts, lights * 3, out_counts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         rt_set_error("bin_rays launch failed: %s", hipGetErrorString(e));
