@@ -591,18 +591,16 @@ k_sweep_raster(const SweepArgs A)
 // triangles' pixel rectangles together (raster_rare_batch): lane k takes triangle k's box, finds
 // its columns (an interval, from the box) and its rows (the block's rows are in ascending order
 // of Y: two binary searches with the hot loop's own comparison) and fetches its planes into LDS
-// -- one wait for memory per quarter tile -- and then the rectangles are worked through one after
-// the other, a rectangle's pixels dealt to the 64 lanes 64 at a time for the inside test of
-// finish_raster.  (Dealing the pixels of all rectangles to the lanes together, as the cell sweep
-// does with its rays, was measured and lost: 2.0 ms of rare path against 1.0 on the million-triangle
-// frame -- a search per pixel for its rectangle, and planes that differ from lane to lane.)
+// -- one wait for memory per quarter tile -- and then the rows of all the rectangles are dealt to the
+// lanes, each cut down to the span its triangle can occupy, and the pixels of the spans dealt to
+// the lanes for the inside test of finish_raster (raster_rare_batch has the details).
 constexpr int kWaveBlockCols = 4096;
 constexpr int kWaveGroup = 2;           // tiles of boxes staged at a time
 
 template <int NL>
 __device__ __forceinline__ void raster_rare_batch(const SweepArgs& A, const float4* qbox, int tri0, unsigned passed,
                                                   int wave_x0, int wave_y0, const float* rows_y, float4 (*qp)[4],
-                                                  int* flags, float Xs0, const float (&YL)[NL], int lane)
+                                                  unsigned qp_at, int* flags, float Xs0, const float (&YL)[NL], int lane)
 {
     constexpr int WW = kWaveBlockCols, WH = 64 * NL;
     constexpr float COLS = (float)RT_RASTER_COLS;
@@ -678,80 +676,90 @@ __device__ __forceinline__ void raster_rare_batch(const SweepArgs& A, const floa
         qp[lane][3] = g4[3 * A.plane_stride];
     }
     wave_lds_sync();
-    // One rectangle after the other (rectangle and planes are wave-uniform: scalar registers and LDS
-    // broadcasts).  A bounding box is mostly empty -- of the pixels of the million-triangle frame's
-    // rectangles one in eighteen is a candidate -- so the rows of a rectangle are first cut down to
-    // the span the triangle can occupy: U, V, det and W = det - U - V are linear in a pixel's X for a
-    // given row, a hit needs U, V, W >= 0 and det > 0, and the sweep's own allowances say how far the
-    // fp32 values of a true hit can lie below that (by at most delta = margin / 32, and en for det).
-    // The span of a row keeps every X with U, V, W > -margin / 2 and det > -2 en -- four half-lines,
-    // so one interval -- rounded outwards and widened by a pixel on either side; a pixel outside it
-    // cannot be a hit, and the pixels inside it get the inside test of finish_raster as before.
-    // Lane r takes row r of the rectangle (64 rows at a time) and works out its span; then the pixels
-    // of the spans are dealt to the lanes 64 at a time.  A.debug_skip == 4: whole rows (for the tests).
-    for (; todo; todo &= todo - 1) {
-        const int k = __builtin_ctzll(todo);
-        const int knx = __builtin_amdgcn_readlane(nx, k), kx = __builtin_amdgcn_readlane(x_lo, k);
-        const int kr = __builtin_amdgcn_readlane(r_lo, k), kny = __builtin_amdgcn_readlane(ny, k);
-        const float4 kP = qp[k][0], kH = qp[k][2], kN = qp[k][3];
-        const float margin = qp[k][1].w;
-        if (A.debug_skip == 2) continue;
-        const float half_w = (float)(A.W / 2);
-        for (int r0 = 0; r0 < kny; r0 += 64) {
-            const int r = r0 + lane;
-            int c_lo = kx, n_r = 0;
-            if (r < kny) {
-                int c_hi = kx + knx - 1;
-                if (margin != INF && A.debug_skip != 4) {       // (INF: no fp32 verdict, every pixel of the box is listed)
-                    const float Y = rows_y[kr + r];
-                    // f(Xs) = g Xs + c for U, V, det and W (Xs = X / COLS as in finish_raster)
-                    const float gU = -kP.x, cU = -__builtin_fmaf(Y, kP.y, kP.z) - kP.w;
-                    const float gV = COLS * kH.x, cV = __builtin_fmaf(Y, kH.y, kH.z);
-                    const float gD = COLS * kN.x, cD = __builtin_fmaf(Y, kN.y, kN.z);
-                    const float gW = gD - gU - gV, cW = cD - cU - cV;
-                    float lo = -INF, hi = INF;
-                    bool none = false;
-                    auto keep = [&](float g, float c, float least) {     // the X with g X + c > least
-                        const float bound = (least - c) / g;
-                        if (g > 0.0f) lo = __builtin_fmaxf(lo, bound);
-                        else if (g < 0.0f) hi = __builtin_fminf(hi, bound);
-                        else if (!(c > least)) none = true;
-                    };
-                    const float least = -0.5f * margin;
-                    keep(gU, cU, least);
-                    keep(gV, cV, least);
-                    keep(gW, cW, least);
-                    keep(gD, cD, -2.0f * kN.w);
-                    // to pixel columns, outwards, and a pixel more on either side
-                    const float pl = __builtin_fmaf(COLS, lo, half_w), ph = __builtin_fmaf(COLS, hi, half_w);
-                    if (none || !(pl <= ph)) {
-                        c_hi = c_lo - 1;
-                    } else {
-                        if (pl > (float)c_lo) c_lo = (int)__builtin_floorf(pl) - 1 > c_lo ? (int)__builtin_floorf(pl) - 1 : c_lo;
-                        if (ph < (float)c_hi) c_hi = (int)__builtin_ceilf(ph) + 1 < c_hi ? (int)__builtin_ceilf(ph) + 1 : c_hi;
-                    }
+    // A bounding box is mostly empty -- of the pixels of the million-triangle frame's rectangles one
+    // in eighteen is a candidate -- so the rows of a rectangle are first cut down to the span the
+    // triangle can occupy: U, V, det and W = det - U - V are linear in a pixel's X for a given row, a
+    // hit needs U, V, W >= 0 and det > 0, and the sweep's own allowances say how far the fp32 values
+    // of a true hit can lie below that (by at most delta = margin / 32, and en for det).  The span
+    // of a row keeps every X with U, V, W > -margin / 2 and det > -2 en -- four half-lines, so one
+    // interval -- rounded outwards and widened by a pixel on either side; a pixel outside it cannot
+    // be a hit, and the pixels inside it get the inside test of finish_raster as before.
+    // The rows of ALL the rectangles are dealt to the lanes 64 at a time (a lane looks up its
+    // rectangle's corner and planes through the lane that owns it), each lane works out its row's
+    // span, and the pixels of those 64 spans are dealt to the lanes 64 at a time in turn.  Small
+    // triangles, a few rows of a few pixels each, fill the lanes that way; one rectangle after the
+    // other, each of them cost a round of its own for its rows and one for its pixels, and a wait
+    // for memory in each.  A.debug_skip == 4: whole rows (for the tests).
+    if (A.debug_skip == 2) return;
+    const float half_w = (float)(A.W / 2);
+    // (plane j of rectangle k, by its LDS address qp_at + ...: the rectangle differs from lane to lane)
+    auto plane = [&](int k, int j) { return lds_read_float4(qp_at + (unsigned)(k * 64 + j * 16)); };
+    const int rows_k = npix > 0 ? ny : 0;
+    const int inclR = wave_scan(rows_k, lane);
+    const int totalR = __builtin_amdgcn_readlane(inclR, 63);
+    const int exclR = inclR - rows_k;
+    int carryR = -1;
+    for (int R0 = 0; R0 < totalR; R0 += 64) {
+        const int k = wave_owner(exclR, rows_k, R0, flags, carryR, lane);    // the rectangle of row item R0 + lane
+        carryR = __builtin_amdgcn_readlane(k, 63);
+        const int kx = __shfl(x_lo, k), knx = __shfl(nx, k);
+        const int row = __shfl(r_lo - exclR, k) + R0 + lane;                 // its row of the block
+        int c_lo = kx, n_r = 0;
+        if (R0 + lane < totalR) {
+            int c_hi = kx + knx - 1;
+            const float margin = plane(k, 1).w;
+            if (margin != INF && A.debug_skip != 4) {       // (INF: no fp32 verdict, every pixel of the box is listed)
+                const float4 kP = plane(k, 0), kH = plane(k, 2), kN = plane(k, 3);
+                const float Y = rows_y[row];
+                // f(Xs) = g Xs + c for U, V, det and W (Xs = X / COLS as in finish_raster)
+                const float gU = -kP.x, cU = -__builtin_fmaf(Y, kP.y, kP.z) - kP.w;
+                const float gV = COLS * kH.x, cV = __builtin_fmaf(Y, kH.y, kH.z);
+                const float gD = COLS * kN.x, cD = __builtin_fmaf(Y, kN.y, kN.z);
+                const float gW = gD - gU - gV, cW = cD - cU - cV;
+                float lo = -INF, hi = INF;
+                bool none = false;
+                auto keep = [&](float g, float c, float least) {     // the X with g X + c > least
+                    const float bound = (least - c) / g;
+                    if (g > 0.0f) lo = __builtin_fmaxf(lo, bound);
+                    else if (g < 0.0f) hi = __builtin_fminf(hi, bound);
+                    else if (!(c > least)) none = true;
+                };
+                const float least = -0.5f * margin;
+                keep(gU, cU, least);
+                keep(gV, cV, least);
+                keep(gW, cW, least);
+                keep(gD, cD, -2.0f * kN.w);
+                // to pixel columns, outwards, and a pixel more on either side
+                const float pl = __builtin_fmaf(COLS, lo, half_w), ph = __builtin_fmaf(COLS, hi, half_w);
+                if (none || !(pl <= ph)) {
+                    c_hi = c_lo - 1;
+                } else {
+                    if (pl > (float)c_lo) c_lo = (int)__builtin_floorf(pl) - 1 > c_lo ? (int)__builtin_floorf(pl) - 1 : c_lo;
+                    if (ph < (float)c_hi) c_hi = (int)__builtin_ceilf(ph) + 1 < c_hi ? (int)__builtin_ceilf(ph) + 1 : c_hi;
                 }
-                n_r = c_hi - c_lo + 1;
-                if (n_r < 0) n_r = 0;
             }
-            // the pixels of the batch's spans, dealt to the lanes 64 at a time (a running sum over the
-            // rows' span lengths; dealing L lanes to a row, L the power of two that holds the longest
-            // span, was measured: one long span idles most lanes, 2.2 ms against 1.6)
-            const int incl = wave_scan(n_r, lane);
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            const int excl = incl - n_r;
-            const int base = c_lo - excl;                   // pixel p of the row's span is column base + p
-            int carry = -1;
-            for (int p0 = 0; p0 < total; p0 += 64) {
-                const int p = p0 + lane;
-                const int q = wave_owner(excl, n_r, p0, flags, carry, lane);     // the row whose span holds pixel p
-                carry = __builtin_amdgcn_readlane(q, 63);
-                const int px = __shfl(base, q) + p;
-                if (p < total) {
-                    const int row = kr + r0 + q;
-                    finish_raster(A, (long)(wave_y0 + row) * A.W + px, tri0 + k, kP, margin, kH, kN,
-                                  (float)(px - A.W / 2) * (1.0f / COLS), rows_y[row]);
-                }
+            n_r = c_hi - c_lo + 1;
+            if (n_r < 0) n_r = 0;
+        }
+        // the pixels of the batch's spans, dealt to the lanes 64 at a time (a running sum over the
+        // rows' span lengths; dealing L lanes to a row, L the power of two that holds the longest
+        // span, was measured: one long span idles most lanes, 2.2 ms against 1.6)
+        const int incl = wave_scan(n_r, lane);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const int excl = incl - n_r;
+        const int base = c_lo - excl;                   // pixel p of the row's span is column base + p
+        const int row_k = (row << 5) | k;               // (k < 32)
+        int carry = -1;
+        for (int p0 = 0; p0 < total; p0 += 64) {
+            const int p = p0 + lane;
+            const int q = wave_owner(excl, n_r, p0, flags, carry, lane);     // the lane whose row's span holds pixel p
+            carry = __builtin_amdgcn_readlane(q, 63);
+            const int px = __shfl(base, q) + p;
+            const int rk = __shfl(row_k, q);
+            if (p < total) {
+                const int prow = rk >> 5, pk = rk & 31;
+                finish_raster(A, (long)(wave_y0 + prow) * A.W + px, tri0 + pk, plane(pk, 0), plane(pk, 1).w, plane(pk, 2), plane(pk, 3),
+                              (float)(px - A.W / 2) * (1.0f / COLS), rows_y[prow]);
             }
         }
     }
@@ -845,7 +853,9 @@ k_sweep_raster_wave(const SweepArgs A)
                 box_at += 16u * kRasterUnroll;
             }
             if (__builtin_expect(passed != 0 && A.debug_skip != 1, 0))
-                raster_rare_batch<NL>(A, qbox, tri0, passed, wave_x0, wave_y0, row_y, plane_lds[wave], owner_lds[wave], Xs0, YL, lane);
+                raster_rare_batch<NL>(A, qbox, tri0, passed, wave_x0, wave_y0, row_y, plane_lds[wave],
+                                      lds_address(&plane_lds[0][0][0]) + (unsigned)wave * (unsigned)sizeof(plane_lds[0]),
+                                      owner_lds[wave], Xs0, YL, lane);
         }
         tiles_done += count;
         __builtin_amdgcn_s_waitcnt(0);

@@ -214,7 +214,8 @@ __device__ __forceinline__ void wave_lds_sync()
 // own store and load would otherwise be all there is.)
 __device__ __forceinline__ int wave_owner(int excl, int n, int p0, int* flags_, int carry, int lane)
 {
-    volatile int* flags = flags_;
+    // (an LDS pointer to the compiler too: volatile accesses through a generic pointer stay generic)
+    volatile __attribute__((address_space(3))) int* flags = (volatile __attribute__((address_space(3))) int*)flags_;
     flags[lane] = -1;
     const int at = excl - p0;
     if (n > 0 && at >= 0 && at < 64) flags[at] = lane;
