@@ -68,7 +68,7 @@ void        rt_shutdown(void);
 int         rt_device_count(void);               /* number of visible HIP devices (0 if none) */
 const char* rt_last_error(void);
 const char* rt_version(void);
-int         rt_set_stream(void* hip_stream);     /* NULL = the default stream */
+int         rt_set_stream(void* hip_stream);     /* NULL = the default stream; waits for the work left on the stream it replaces */
 
 typedef struct rt_scene rt_scene;                /* device-resident mesh, opaque */
 typedef struct rt_obj rt_obj;                    /* a loaded .obj file (host side), opaque */
@@ -118,7 +118,10 @@ int rt_scene_set_textures(rt_scene* sc, int num_textures, const int* w, const in
 /* mat_mult.cu:8-28 on the device-resident master copy: eye = m * object for every vertex
  * (slot 0 included, as driver.c:110 does), then the per-triangle fp32 sweep buffer
  * (v0, e1, e2 planes) is rebuilt.  The object-space master is never overwritten, so no
- * inverse pass (driver.c:202) is needed and no drift accumulates over frames. */
+ * inverse pass (driver.c:202) is needed and no drift accumulates over frames.
+ * The call queues the work on the library's stream and returns (m is read before it does); the
+ * calls that use the eye-space geometry are ordered behind it, and a failure of the queued work
+ * is reported by the next call that waits for the device. */
 int rt_scene_transform(rt_scene* sc, const double m[4][4]);
 /* Applies m to the master copy itself (what obj_reader.c:288 does at load time). */
 int rt_scene_bake(rt_scene* sc, const double m[4][4]);

@@ -104,7 +104,12 @@ extern "C" void rt_shutdown(void)
 
 extern "C" int rt_set_stream(void* hip_stream)
 {
-    rt_g().stream = static_cast<hipStream_t>(hip_stream);
+    // (calls such as rt_scene_transform leave work on the stream; what follows on another stream
+    // must not overtake it)
+    RtGlobal& g = rt_g();
+    hipStream_t next = static_cast<hipStream_t>(hip_stream);
+    if (g.inited && next != g.stream) RT_HIP(hipStreamSynchronize(g.stream));
+    g.stream = next;
     return RT_OK;
 }
 
@@ -476,51 +481,35 @@ static int transform_into(rt_scene* sc, const double m[4][4], bool bake)
         rt_set_error("transform: no vertices set");
         return RT_E_STATE;
     }
+    // Nothing here waits for the device: the matrix travels with the launch, and the one number
+    // the host ever needs back (the extent of the eye-space vertices, for sweeps of rays in
+    // general position) is fetched when such rays are traced.  Whatever follows on the library's
+    // stream is ordered behind the transform; rt_set_stream drains the stream it leaves.
     hipStream_t st = rt_g().stream;
-    DevBuf& mdev = sc->mat_dev;     // kept with the scene: no allocation per frame
-    RT_TRY(mdev.reserve(16 * sizeof(double)));
-    int rc = RT_OK;
-    do {
-        if (hipMemcpyAsync(mdev.p, m, 16 * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
-            rt_set_error("transform: matrix upload failed");
-            rc = RT_E_HIP;
-            break;
-        }
-        const int n = sc->num_v + 1;
-        if (bake) {
-            rc = rt_launch_transform(mdev.as<double>(), sc->ox.as<double>(), sc->oy.as<double>(),
-                                     sc->oz.as<double>(), sc->ox.as<double>(), sc->oy.as<double>(),
-                                     sc->oz.as<double>(), n, nullptr, st);
-            sc->transformed = false;
-        } else {
-            if (!sc->iA.p || !sc->scratch_max.p) {
-                rt_set_error("transform: no triangles set");
-                rc = RT_E_STATE;
-                break;
-            }
-            if (hipMemsetAsync(sc->scratch_max.p, 0, 4, st) != hipSuccess) { rc = RT_E_HIP; break; }
-            rc = rt_launch_transform(mdev.as<double>(), sc->ox.as<double>(), sc->oy.as<double>(),
-                                     sc->oz.as<double>(), sc->ex.as<double>(), sc->ey.as<double>(),
-                                     sc->ez.as<double>(), n, sc->scratch_max.as<unsigned>(), st);
-            if (rc) break;
-            rc = rt_launch_pack(sc, st, false, true);
-            if (rc) break;
-            sc->planes_ready = false;
-            sc->transformed = true;
-        }
-        float radius = 0;
-        if (!bake && hipMemcpyAsync(&radius, sc->scratch_max.p, sizeof radius, hipMemcpyDeviceToHost,
-                                    st) != hipSuccess) {
-            rc = RT_E_HIP;
-            break;
-        }
-        if (hipStreamSynchronize(st) != hipSuccess) {
-            rt_set_error("transform: kernel failed: %s", hipGetErrorString(hipGetLastError()));
-            rc = RT_E_HIP;
-        }
-        if (!bake) sc->radius = (double)radius;
-    } while (0);
-    return rc;
+    RtMat12 mat;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) mat.v[4 * r + c] = m[r][c];
+    const int n = sc->num_v + 1;
+    if (bake) {
+        RT_TRY(rt_launch_transform(mat, sc->ox.as<double>(), sc->oy.as<double>(), sc->oz.as<double>(),
+                                   sc->ox.as<double>(), sc->oy.as<double>(), sc->oz.as<double>(), n, nullptr, st));
+        sc->transformed = false;
+        return RT_OK;
+    }
+    if (!sc->iA.p || !sc->scratch_max.p) {
+        rt_set_error("transform: no triangles set");
+        return RT_E_STATE;
+    }
+    RT_HIP(hipMemsetAsync(sc->scratch_max.p, 0, 4, st));
+    sc->transformed = false;
+    RT_TRY(rt_launch_transform(mat, sc->ox.as<double>(), sc->oy.as<double>(), sc->oz.as<double>(),
+                               sc->ex.as<double>(), sc->ey.as<double>(), sc->ez.as<double>(), n,
+                               sc->scratch_max.as<unsigned>(), st));
+    RT_TRY(rt_launch_pack(sc, st, false, true));
+    sc->planes_ready = false;
+    sc->radius_ready = false;
+    sc->transformed = true;
+    return RT_OK;
 }
 
 extern "C" int rt_scene_transform(rt_scene* sc, const double m[4][4]) { return transform_into(sc, m, false); }
@@ -534,6 +523,7 @@ extern "C" int rt_scene_get_eye_vertices(rt_scene* sc, double* x, double* y, dou
         return RT_E_STATE;
     }
     const size_t bytes = sizeof(double) * (size_t)(sc->num_v + 1);
+    RT_HIP(hipStreamSynchronize(rt_g().stream));        // the transform may still be running
     RT_HIP(hipMemcpy(x, sc->ex.p, bytes, hipMemcpyDeviceToHost));
     RT_HIP(hipMemcpy(y, sc->ey.p, bytes, hipMemcpyDeviceToHost));
     RT_HIP(hipMemcpy(z, sc->ez.p, bytes, hipMemcpyDeviceToHost));
@@ -1033,6 +1023,13 @@ static int trace_rays_impl(rt_scene* sc, const RayWorkspace* static_ws, int n, c
     if (!sc->planes_ready) {        // first rays in general position since the transform
         RT_TRY(rt_launch_pack(sc, st, true, false));
         sc->planes_ready = true;
+    }
+    if (!sc->radius_ready) {
+        float radius = 0;
+        RT_HIP(hipMemcpyAsync(&radius, sc->scratch_max.p, sizeof radius, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipStreamSynchronize(st));
+        sc->radius = (double)radius;
+        sc->radius_ready = true;
     }
     SweepArgs a{};
     a.planes = sc->planes.as<float4>(); a.plane_stride = sc->num_tris_padded;

@@ -138,6 +138,7 @@ struct rt_scene {
     int num_tris_padded = 0;
     bool transformed = false;
     double radius = 0;          // largest |coordinate| of the eye-space vertices (host copy)
+    bool radius_ready = false;  // ... fetched from scratch_max when rays in general position are first traced after a transform
 
     // object-space master + eye-space working copy, fp64 SoA, 1-indexed (slot 0 carried along)
     DevBuf ox, oy, oz, ex, ey, ez;
@@ -229,6 +230,13 @@ int rt_device_cus();        // compute units of the device (cached; every device
 // ---------------------------------------------------------------- launchers (defined per .hip file)
 // rt_transform.hip
 int rt_launch_transform(const double* m16, const double* x, const double* y, const double* z,
+                        double* X, double* Y, double* Z, int n, unsigned* max_bits, hipStream_t st);
+// ... with rows 0..2 of the matrix passed by value
+struct RtMat12 {
+    double v[12];
+    __host__ __device__ double operator[](int i) const { return v[i]; }
+};
+int rt_launch_transform(const RtMat12& m, const double* x, const double* y, const double* z,
                         double* X, double* Y, double* Z, int n, unsigned* max_bits, hipStream_t st);
 // planes: the general sweep's planes (rt_sweep.hip); verts: the exact pass's copy of the triangles.
 // A transform writes the copy only; the planes follow when rays in general position are traced

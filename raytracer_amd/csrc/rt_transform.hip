@@ -18,8 +18,11 @@ namespace {
 
 constexpr int kTransformPoints = 8;     // points per lane of k_transform
 
+// M: the matrix, rows 0..2 -- in device memory (const double*) or passed with the launch (RtMat12:
+// no upload, nothing of the caller's the device still reads when the launch call returns)
+template <class M>
 __global__ void __launch_bounds__(RT_WG)
-k_transform(const double* __restrict__ m, const double* x, const double* y, const double* z,
+k_transform(const M m, const double* x, const double* y, const double* z,
             double* X, double* Y, double* Z, int n, unsigned* __restrict__ max_bits)
 {
     // kTransformPoints points per lane, so that the largest coordinate costs one atomic per
@@ -398,7 +401,22 @@ int rt_launch_transform(const double* m16, const double* x, const double* y, con
 {
     if (n <= 0) return RT_OK;
     const int per_wg = RT_WG * kTransformPoints;
-    hipLaunchKernelGGL(k_transform, dim3((n + per_wg - 1) / per_wg), dim3(RT_WG), 0, st, m16, x, y, z,
+    hipLaunchKernelGGL(k_transform<const double*>, dim3((n + per_wg - 1) / per_wg), dim3(RT_WG), 0, st, m16, x, y, z,
+                       X, Y, Z, n, max_bits);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        rt_set_error("transform launch failed: %s", hipGetErrorString(e));
+        return RT_E_HIP;
+    }
+    return RT_OK;
+}
+
+int rt_launch_transform(const RtMat12& m, const double* x, const double* y, const double* z,
+                        double* X, double* Y, double* Z, int n, unsigned* max_bits, hipStream_t st)
+{
+    if (n <= 0) return RT_OK;
+    const int per_wg = RT_WG * kTransformPoints;
+    hipLaunchKernelGGL(k_transform<RtMat12>, dim3((n + per_wg - 1) / per_wg), dim3(RT_WG), 0, st, m, x, y, z,
                        X, Y, Z, n, max_bits);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
