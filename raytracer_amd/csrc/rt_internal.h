@@ -436,6 +436,7 @@ struct CellArgs {
     int num_tris_padded;
     int tri_begin, tri_end; // tile-aligned
     int fine_log2;          // every cell is cut into 2^fine x 2^fine fine cells: the grid the rays are sorted and looked up by
+    int tile_parts;         // 1, 2 or 4: a workgroup takes every tile of its chunk whole, or a half or a quarter of each wave's 32 triangles (blockIdx.y = chunk * tile_parts + part)
     const int* table;       // fine cells + 1 entries: rays in the fine cells before this one (a set's fine cells row by row
                             // over its whole grid); the rays of fine cell c are rays[table[c] .. table[c + 1])
     float2* rays;           // sorted by fine cell: (u, v); u = NaN once the ray has retired
@@ -451,7 +452,7 @@ struct CellArgs {
 struct CellPlan {
     CellArgs args;
     int cells_per_lane;     // 2048, 512, 128 or 32: the kernel shape
-    int chunks;             // triangle chunks (blockIdx.y)
+    int chunks;             // triangle chunks (blockIdx.y = chunk * args.tile_parts + part)
     long cells, footprints, rays;
     int fine_log2;          // = args.fine_log2
     const int* wide;        // per set: the triangles swept ray by ray instead (k_cell_boxes)

@@ -319,10 +319,16 @@ k_sweep_cells(const CellArgs A)
     // and a large triangle has many rays inside its square: dealt out tile by tile every chunk
     // gets its share of those, and every chunk meets its largest triangles first (rays that
     // are occluded retire early).
+    // With few tiles (a mesh of 70 000 triangles has 540) and few footprints, a chunk of one tile
+    // still leaves a wave 32 triangles whose rays it tests batch after batch, each batch waiting
+    // for memory: the launch then lasts as long as its unluckiest wave.  tile_parts = 2 or 4 deals
+    // every wave's 32 triangles of a tile to as many workgroups.
+    const int parts = A.tile_parts, chunk = (int)blockIdx.y / parts, part = (int)blockIdx.y - chunk * parts;
+    const int per_wave = (RT_TILE / 4) / parts, wave_first = wave * (RT_TILE / 4) + part * per_wave;
     const int t_first = A.tri_begin / RT_TILE, t_count = A.tri_end / RT_TILE - t_first;
-    const int stride = gridDim.y;
-    const int t0 = t_first + blockIdx.y;
-    const int mine = (int)blockIdx.y < t_count ? (t_count - (int)blockIdx.y + stride - 1) / stride : 0;
+    const int stride = (int)gridDim.y / parts;
+    const int t0 = t_first + chunk;
+    const int mine = chunk < t_count ? (t_count - chunk + stride - 1) / stride : 0;
     auto group = [&](int g) { return mine - g < kGroup ? mine - g : kGroup; };
     unsigned tested = 0, visited = 0, entered = 0;
     if (mine > 0) {
@@ -337,16 +343,16 @@ k_sweep_cells(const CellArgs A)
             stage_cell_boxes(boxes, t0 + (g + kGroup) * stride, stride, group(g + kGroup), tile[buf ^ 1], wave, lane);
         const float4* __restrict__ base = tile[buf];
         for (int sub = 0; sub < count; ++sub) {
-            const int tri0 = (t0 + (g + sub) * stride) * RT_TILE + wave * (RT_TILE / 4);
+            const int tri0 = (t0 + (g + sub) * stride) * RT_TILE + wave_first;
             // (the address in a vector register the compiler cannot see through, advanced once per
             // kUnroll triangles, the reads at immediate offsets, one triangle ahead; the last read
             // of a quarter touches the entry behind it and is not used)
-            const float4* qbox = base + sub * RT_TILE + wave * (RT_TILE / 4);
+            const float4* qbox = base + sub * RT_TILE + wave_first;
             unsigned box_at = lds_address(qbox);
             asm volatile("" : "+v"(box_at));
             float4 next = lds_read_float4(box_at);
             unsigned passed = 0;            // the quarter's triangles with a cell of the wave in their box
-            for (int j4 = 0; j4 < RT_TILE / 4; j4 += kUnroll) {
+            for (int j4 = 0; j4 < per_wave; j4 += kUnroll) {
 #pragma unroll
                 for (int k = 0; k < kUnroll; ++k) {
                     const float4 box = next;
@@ -364,14 +370,22 @@ k_sweep_cells(const CellArgs A)
         __syncthreads();
     }
     if (A.ray_pairs) {          // [0]: (ray, triangle) pairs tested one by one; [2]: cell-table look-ups
+        // (statistics, only when the library is profiling: summed over the workgroup first -- tens of
+        // thousands of waves adding to the same three counters one by one showed up in the launch
+        // time they were there to measure)
+        __shared__ unsigned stat_lds[RT_WG / 64][3];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             tested += __shfl_xor(tested, off);
             visited += __shfl_xor(visited, off);
         }
-        if (lane == 0 && tested) atomicAdd(A.ray_pairs, (unsigned long long)tested);
-        if (lane == 0 && visited) atomicAdd(A.ray_pairs + 2, (unsigned long long)visited);
-        if (lane == 0 && entered) atomicAdd(A.ray_pairs + 3, (unsigned long long)entered);   // (wave-uniform)
+        if (lane == 0) { stat_lds[wave][0] = tested; stat_lds[wave][1] = visited; stat_lds[wave][2] = entered; }
+        __syncthreads();
+        if (tid < 3) {
+            unsigned long long sum = 0;
+            for (int w = 0; w < RT_WG / 64; ++w) sum += stat_lds[w][tid];
+            if (sum) atomicAdd(A.ray_pairs + (tid == 0 ? 0 : tid + 1), sum);
+        }
     }
 }
 
@@ -682,6 +696,19 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
         if (c > max_chunks) c = max_chunks;
         if (forced_chunks) c = forced_chunks > tiles ? tiles : forced_chunks;
         plan->chunks = c < 1 ? 1 : (int)c;
+        // one tile per chunk, still fewer than four rounds of workgroups, and many rays for every
+        // triangle (10 and more): the tiles are cut as well.  RT_AMD_CELLS_PARTS = 1, 2 or 4 forces
+        // the cut.  Frames at 3840 x 2160 with 1 / 2 / 4 parts: 69 k-triangle sphere (43 rays per
+        // triangle in the main level) 3.70 / 3.57 / 3.42 ms, 100 k-triangle torus (13) 2.52 / 2.38 /
+        // 2.41; the 100 k soup at 1920 x 1080 (8 rays per triangle) 1.66 / 1.70 / 1.77 -- no cut there.
+        int parts = 1;
+        if (plan->chunks == tiles && (double)plan->rays >= 10.0 * (double)np)
+            while (parts < 4 && plan->footprints * plan->chunks * parts < 4 * slots) parts *= 2;
+        if (const char* e = getenv("RT_AMD_CELLS_PARTS")) {
+            const int p = atoi(e);
+            if (p == 1 || p == 2 || p == 4) parts = p;
+        }
+        plan->args.tile_parts = parts;
     }
 
     // workspace: keys, records and slots (by ray, by cell); the table, the per-cell counts and
@@ -774,7 +801,7 @@ int rt_cells_launch(const CellPlan& plan, hipStream_t st)
             return RT_E_HIP;
         }
     }
-    const dim3 grid((unsigned)plan.footprints, (unsigned)plan.chunks);
+    const dim3 grid((unsigned)plan.footprints, (unsigned)(plan.chunks * plan.args.tile_parts));
     switch (plan.cells_per_lane) {
     case 2048: hipLaunchKernelGGL(k_sweep_cells<2048>, grid, dim3(RT_WG), 0, st, plan.args); break;
     case 512: hipLaunchKernelGGL(k_sweep_cells<512>, grid, dim3(RT_WG), 0, st, plan.args); break;
