@@ -1536,8 +1536,12 @@ void rt_raster_shape(int W, int rows, int tiles, bool regular, int* pixels_per_l
         }
         if (best) {
             const long wgs = rt_raster_tiles(W, rows, best, -1);
+            // (the chunks themselves may be twice as many as the cap the shapes are compared under: a
+            // million triangles at 3840x2160 sweep in 1.40 ms with 1024 chunks, 1.23 with 2048, 1.20
+            // with 3072, 1.16 with 4096 and 1.18 with one tile per chunk)
+            const long most = tiles < 2 * cap ? (tiles < 1 ? 1 : tiles) : 2 * cap;
             long c = (rounds * slots + wgs - 1) / wgs;
-            if (c > max_chunks) c = max_chunks;
+            if (c > most) c = most;
             *pixels_per_lane = best;
             *chunks = c < 1 ? 1 : (int)c;
             *waves_x = -1;

