@@ -108,6 +108,38 @@ def test_every_shape_of_the_cell_sweep(shape, cells_per_ray, fine, sort, monkeyp
     sc.close()
 
 
+@pytest.mark.parametrize("parts", ["1", "2", "4", "8"])
+@pytest.mark.parametrize("shape", ["2048,20", "128,20", "8,20"])
+@pytest.mark.parametrize("fine", [None, "4"])
+def test_tiles_cut_in_parts(parts, shape, fine, monkeypatch):
+    """A tile's triangles dealt to 1, 2, 4 or 8 workgroups (every wave sweeps 32, 16, 8 or 4 of a
+    tile's triangles), with one tile per chunk as in the launches that choose the cut themselves,
+    and with the fine cells the sweep picks itself or four per ray: equal to the ray-by-ray sweep."""
+    mesh = scenes.with_materials(scenes.torus(2500))      # 20 tiles
+    fr = kernel.driver_frame(11)
+    W, H = 230, 110
+    sc = kernel.Scene(mesh)
+    sc.transform(kernel.frame_matrix(fr, "obmat"))
+    monkeypatch.setenv("RT_AMD_SHADOW_LATTICE", "0")
+    plain = render(sc, fr, W, H)
+    monkeypatch.setenv("RT_AMD_SHADOW_LATTICE", "1")
+    monkeypatch.setenv("RT_AMD_CELLS_FORCE", shape)
+    monkeypatch.setenv("RT_AMD_CELLS_PARTS", parts)
+    if fine:
+        monkeypatch.setenv("RT_AMD_CELLS_FINE", fine)
+    kernel.profile_enable(True)
+    try:
+        kernel.profile_reset()
+        lattice = render(sc, fr, W, H)
+        p = kernel.profile_get()
+    finally:
+        kernel.profile_enable(False)
+    assert p.cell_launches >= 1 and p.cell_ray_pairs > 0
+    assert (plain["hit"] >= 0).float().mean() > 0.2
+    same(lattice, plain)
+    sc.close()
+
+
 def test_lattice_against_the_oracle_directly():
     """A shaded frame with the lattice on against the CPU oracle (not only against the other sweep)."""
     from oracle import oracle as O
