@@ -240,7 +240,7 @@ extern "C" int rt_scene_destroy(rt_scene* sc)
                       &sc->iAt, &sc->iBt, &sc->iCt, &sc->imtl, &sc->mats, &sc->tex_desc, &sc->planes, &sc->planes_apex, &sc->tri_verts, &sc->tri_normals,
                       &sc->scratch_max, &sc->mat_dev, &sc->ws_partials, &sc->ws_frame, &sc->planes_light, &sc->ws_sort_tri, &sc->ws_cnt, &sc->ws_list, &sc->ws_ovf, &sc->ws_besthi, &sc->ws_axis,
                       &sc->ws_counters, &sc->ws_hit, &sc->ws_tuv, &sc->ws_shS, &sc->ws_shE,
-                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_live, &sc->ws_bin_pad, &sc->ws_occid, &sc->ws_sort, &sc->tri_order, &sc->tri_scatter,
+                      &sc->ws_occ, &sc->ws_act0, &sc->ws_act1, &sc->ws_act2, &sc->ws_tails, &sc->ws_live, &sc->ws_bin_pad, &sc->ws_occid, &sc->ws_sort, &sc->tri_order, &sc->tri_scatter,
                       &sc->ws_cell_rays, &sc->ws_cell_table, &sc->ws_cell_boxes, &sc->ws_cell_wide};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : sc->tex_data) b.release();
@@ -877,6 +877,7 @@ static int anyhit_ranges(rt_scene* sc, SweepArgs a, int n, int sets, long stride
         a.tri_begin = begin; a.tri_end = end;
         a.resume = begin > 0;
         a.active = indexed ? act[cur] : nullptr;
+        a.tails = sc->ws_tails.as<float4>();
         a.live_counts = indexed ? live_dev[cur] : nullptr;
         a.n_rays = indexed ? live : n;          // indexed: (a bound on) the largest set, sizes the grid
         a.total_rays = total;
@@ -986,6 +987,7 @@ static int anyhit_buffers(rt_scene* sc, size_t entries)
 {
     RT_TRY(sc->ws_act0.reserve(sizeof(int32_t) * entries));
     RT_TRY(sc->ws_act1.reserve(sizeof(int32_t) * entries));
+    RT_TRY(sc->ws_tails.reserve(sizeof(float4) * entries));
     RT_TRY(sc->ws_live.reserve(sizeof(int) * (3 + RT_COMPACT_SLICES) * RT_APEX_SETS));   // counts + the compaction's slice sums
     RT_TRY(sc->ws_bin_pad.reserve(sizeof(int) * RT_BIN_COUNT_STRIDE * RT_APEX_SETS));
     return RT_OK;

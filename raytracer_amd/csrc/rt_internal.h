@@ -184,7 +184,7 @@ struct rt_scene {
 
     // per-call workspaces (grow-only)
     DevBuf ws_cnt, ws_list, ws_ovf, ws_counters, ws_besthi, ws_partials, ws_frame, ws_axis;
-    DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_act2, ws_live, ws_bin_pad, ws_occid, ws_sort;
+    DevBuf ws_hit, ws_tuv, ws_shS, ws_shE, ws_occ, ws_act0, ws_act1, ws_act2, ws_tails, ws_live, ws_bin_pad, ws_occid, ws_sort;
     // the cell-lattice any-hit sweep (rt_sweep_cells.hip): sort space and ray records, the cell
     // table, the triangles' boxes in cell units
     DevBuf ws_cell_rays, ws_cell_table, ws_cell_boxes, ws_cell_wide;
@@ -301,6 +301,10 @@ struct SweepArgs {
     int n_rays;
     const double *S, *E;    // 3 doubles per ray
     const int32_t* active;  // indexed mode: n_rays ray numbers to work on (else nullptr)
+    float4* tails;          // apex any-hit sweep: scratch beside `active`, one entry per listed ray -- (len, sig, the
+                            // ray's number as bits, -), written by every workgroup for its own rays before its tile
+                            // loop and read back in the rare path (what would otherwise be two dependent fetches
+                            // and an fp64 square root there, or 24 registers more)
     double scene_radius;    // largest |coordinate| of the eye-space vertices (general-position sweep)
     // triangle range of this launch, tile-aligned; resume = pick up cnt[] left by an earlier range
     int tri_begin, tri_end;

@@ -879,20 +879,9 @@ struct ApexRay {
 };
 
 // What only the rare path needs of a ray is not kept in registers (it would cost the hot loop a
-// wave of occupancy) but read again: its number, and from its end points
+// wave of occupancy) but left in memory by the kernel's prologue (SweepArgs::tails): its number,
 //   len = |apex - S|, the ray parameter of the apex along the unit direction, and
 //   sig = 1 / (unit direction)_k, so that D' = sig * unit direction.
-template <int AX>
-__device__ __forceinline__ void ray_tail(const SweepArgs& A, int sl, float& len, float& sig)
-{
-    const double* s = A.S + 3 * (long)sl;
-    const double* e = A.E + 3 * (long)sl;
-    const double dx = e[0] - s[0], dy = e[1] - s[1], dz = e[2] - s[2];
-    const double l = __builtin_sqrt(dx * dx + dy * dy + dz * dz);
-    len = (float)l;
-    sig = (float)(l / (AX == 0 ? dx : (AX == 1 ? dy : dz)));
-}
-
 template <int AX>
 __device__ __forceinline__ float dot_ax(float u, float v, const float4& p)
 {
@@ -904,7 +893,10 @@ __device__ __forceinline__ float dot_ax(float u, float v, const float4& p)
 // The rest of the inside test for one ray (u, v = minor components of D') that passed the slab
 // test of triangle `tri`; Hh, N = the triangle's planes 2 and 3.  Returns true when the ray
 // retires.  What only this path needs of a ray -- its number, len and sig -- is read again from
-// memory rather than kept in registers.
+// memory rather than kept in registers: one 16-byte entry of A.tails, written by the prologue of
+// k_sweep_apex (read through the ray list and recomputed from the ray's end points here, it was
+// two dependent fetches and an fp64 square root and division for every ray that passed a
+// triangle's inside test).
 template <int AX>
 __device__ __forceinline__ bool finish_apex(const SweepArgs& A, float u, float v, long jr, int tri,
                                             const Tri2& q, const float4& Hh, const float4& N)
@@ -918,9 +910,10 @@ __device__ __forceinline__ bool finish_apex(const SweepArgs& A, float u, float v
         const float w = __builtin_fmaf(d, d, -a) - b;
         const float m3 = __builtin_fminf(__builtin_fminf(a, b), w);
         if (!(__builtin_fmaf(margin, __builtin_fabsf(d), m3) > 0.0f)) return false;
-        const int sl = A.active[jr];
-        float len, sig;
-        ray_tail<AX>(A, sl, len, sig);
+        // (the ray's number, len and sig: from the entry the kernel's prologue left for this ray)
+        const float4 tl = A.tails[jr];
+        const int sl = __float_as_int(tl.z);
+        const float len = tl.x, sig = tl.y;
         // The triangle's plane meets the line apex + tau * D' at tau = k / (D'.nn).  Along the
         // unit direction, from S: t = len + sig * tau (the reference's t times len; only its
         // sign matters for an any-hit query, triangle_intersection.cu:169).
@@ -930,7 +923,7 @@ __device__ __forceinline__ bool finish_apex(const SweepArgs& A, float u, float v
                                 A.occ_id ? A.occ_id + sl : nullptr, A.tri_order ? A.tri_order[tri] : tri,
                                 a, b, w, d, T, len, margin, N.w, U22 * __builtin_fabsf(T));
     }
-    const int sl = A.active[jr];
+    const int sl = __float_as_int(A.tails[jr].z);
     const int at = atomicAdd(A.cnt + sl, 1) & RT_CNT_MASK;
     if (at < RT_LIST_K) A.list[(long)sl * RT_LIST_K + at] = A.tri_order ? A.tri_order[tri] : tri;
     return false;
@@ -1236,6 +1229,7 @@ k_sweep_apex(SweepArgs A)
     if (A.occ_id) A.occ_id += light * A.light_ray_stride;
     if (A.tri_order) A.tri_order += light * A.tri_order_stride;
     A.active += set * A.light_ray_stride;
+    A.tails += set * A.light_ray_stride;
     A.n_rays = A.live_counts[set];
     if ((long)blockIdx.x * (RT_WG * R) >= A.n_rays) return;     // the grid is sized for the largest set
 
@@ -1258,6 +1252,7 @@ k_sweep_apex(SweepArgs A)
             D[0] = e[0] - s[0]; D[1] = e[1] - s[1]; D[2] = e[2] - s[2];
             const double len = __builtin_sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
             const double sig = len / (axis == 0 ? D[0] : (axis == 1 ? D[1] : D[2]));
+            A.tails[j] = make_float4((float)len, (float)sig, __int_as_float(sl), 0.0f);     // for finish_apex
             // listed rays have a finite, non-zero direction (k_bin_rays); be safe regardless
             if (!(len > 0) || !(sig == sig) || sig > 1e300 || sig < -1e300) valid = false;
             // the ray's count and flags live in cnt[] (zeroed by the host before the first range)

@@ -4,7 +4,7 @@
 set -uo pipefail
 out="$1"; mkdir -p "$out"; export TMPDIR=/tmp
 run() { name="$1"; shift
-  timeout -s KILL 170 rocprofv3 --kernel-trace "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$out/$name.log"; }; }
+  timeout -s KILL 170 rocprofv3 --kernel-trace "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline ${BENCH_ARGS:-} > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$out/$name.log"; }; }
 run pmc_issue --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU
 run pmc_mem --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_BRANCH
 run pmc_tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA_RDREQ_sum
