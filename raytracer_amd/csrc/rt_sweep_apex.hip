@@ -1240,23 +1240,41 @@ k_sweep_apex(SweepArgs A)
     // entries the wave pays for); ray r of this lane: active[j0 + r * 64]
     const long j0 = (long)blockIdx.x * (RT_WG * R) + wave * (64 * R) + lane;
 
+    // The rays' numbers and states first, all in flight together (entry 0 stands in beyond the
+    // list's end: a fetch under a condition is waited for inside its branch), then ray after ray
+    // its end points, the next ray's on their way while this one's direction is worked out.
+    int sl_[R], state_[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) sl_[r] = A.active[j0 + r * 64 < A.n_rays ? j0 + r * 64 : 0];
+#pragma unroll
+    for (int r = 0; r < R; ++r) state_[r] = A.cnt[sl_[r]];
+    double nS[3], nE[3];
+    {
+        const double* s = A.S + 3 * (long)sl_[0];
+        const double* e = A.E + 3 * (long)sl_[0];
+        nS[0] = s[0]; nS[1] = s[1]; nS[2] = s[2];
+        nE[0] = e[0]; nE[1] = e[1]; nE[2] = e[2];
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const long j = j0 + r * 64;
         bool valid = j < A.n_rays;
-        double D[3] = {0, 0, 0};
-        if (valid) {
-            const int sl = A.active[j];
-            const double* s = A.S + 3 * (long)sl;
-            const double* e = A.E + 3 * (long)sl;
-            D[0] = e[0] - s[0]; D[1] = e[1] - s[1]; D[2] = e[2] - s[2];
+        const double cS[3] = {nS[0], nS[1], nS[2]}, cE[3] = {nE[0], nE[1], nE[2]};
+        if (r + 1 < R) {
+            const double* s = A.S + 3 * (long)sl_[r + 1 < R ? r + 1 : r];
+            const double* e = A.E + 3 * (long)sl_[r + 1 < R ? r + 1 : r];
+            nS[0] = s[0]; nS[1] = s[1]; nS[2] = s[2];
+            nE[0] = e[0]; nE[1] = e[1]; nE[2] = e[2];
+        }
+        double D[3] = {cE[0] - cS[0], cE[1] - cS[1], cE[2] - cS[2]};
+        {
             const double len = __builtin_sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
             const double sig = len / (axis == 0 ? D[0] : (axis == 1 ? D[1] : D[2]));
-            A.tails[j] = make_float4((float)len, (float)sig, __int_as_float(sl), 0.0f);     // for finish_apex
+            if (valid) A.tails[j] = make_float4((float)len, (float)sig, __int_as_float(sl_[r]), 0.0f);     // for finish_apex
             // listed rays have a finite, non-zero direction (k_bin_rays); be safe regardless
             if (!(len > 0) || !(sig == sig) || sig > 1e300 || sig < -1e300) valid = false;
             // the ray's count and flags live in cnt[] (zeroed by the host before the first range)
-            if (A.cnt[sl] & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) valid = false;
+            if (state_[r] & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) valid = false;
         }
         const double du = (axis == 0 ? D[1] : D[0]), dv = (axis == 2 ? D[1] : D[2]);
         const double dk = axis == 0 ? D[0] : (axis == 1 ? D[1] : D[2]);
