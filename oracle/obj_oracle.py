@@ -3,8 +3,8 @@ files.  TEST INFRASTRUCTURE ONLY -- the product's loader is raytracer_amd/csrc/r
 
 obj_reader.c cannot be compiled here (MSVC CRT calls and SDL headers), so this follows its
 source text: the scanf-driven second pass (obj_reader.c:628-726), scan_face (:93-237) and
-center_and_scale_object (:239-289).  The one behaviour pinned by an actual run of the
-reference recorded by the survey is the quad split: `f 1 2 3 4` -> (1,2,3) and (1,3,4).
+center_and_scale_object (:239-289).  The one behaviour pinned by a recorded run of the
+reference's scan_face is the quad split: `f 1 2 3 4` -> (1,2,3) and (1,3,4).
 Format-1 faces store the vertex index, not the address the reference stores (:98-100).
 """
 from __future__ import annotations

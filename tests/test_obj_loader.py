@@ -60,7 +60,7 @@ def test_quad_split_in_all_four_formats(tmp_path, fmt, face):
     p.write_text(QUAD + face)
     rc, got = load_view(str(p))
     assert rc == 0
-    # obj_reader.c:167-231 (and the survey's recorded run of the reference): (1,2,3) + (1,3,4)
+    # obj_reader.c:167-231 (and a recorded run of the reference's scan_face): (1,2,3) + (1,3,4)
     assert got["num_tris"] == 2
     assert (got["A"].tolist(), got["B"].tolist(), got["C"].tolist()) == ([1, 1], [2, 3], [3, 4])
     if fmt in (1, 2):       # one synthesised, un-normalised face normal AB x AC shared by both halves
