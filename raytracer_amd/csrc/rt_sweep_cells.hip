@@ -405,7 +405,7 @@ struct CellKeySets {
 __global__ void __launch_bounds__(RT_WG)
 k_cell_keys(const double* __restrict__ S, const double* __restrict__ E, const int32_t* __restrict__ lists,
             long stride, const int32_t* __restrict__ cnt, CellKeySets ks, unsigned* __restrict__ keys,
-            int* __restrict__ hist, float2* __restrict__ rec, float2* __restrict__ len_sig,
+            int* __restrict__ hist, int* __restrict__ ranks, float2* __restrict__ rec, float2* __restrict__ len_sig,
             int32_t* __restrict__ slot)
 {
     const CellSet cs = ks.set[blockIdx.y];
@@ -440,25 +440,26 @@ k_cell_keys(const double* __restrict__ S, const double* __restrict__ E, const in
         const long g = cs.ray_base + i;
         const unsigned key = key_base + (unsigned)((row << (cs.gu_log2 + fl)) + col);
         keys[g] = key;
-        atomicAdd(&hist[key], 1);               // rays per fine cell
+        ranks[g] = atomicAdd(&hist[key], 1);    // rays per fine cell; the old count is the ray's place among its cell's
         rec[g] = make_float2(valid ? u : qnan, v);
         len_sig[g] = make_float2((float)len, (float)sig);
         slot[g] = (int32_t)sl;
     }
 }
 
-// The records into cell order: a ray's place is its cell's first (table) plus what is left of
-// the cell's count when the ray takes one off (the order of a cell's rays among themselves is
-// whatever the atomics make it; no result depends on it).
+// The records into cell order: a ray's place is its cell's first (table) plus the number of its
+// cell's rays counted before it (the order of a cell's rays among themselves is whatever the
+// atomics of k_cell_keys made it; no result depends on it).  No atomics here: a second one per ray
+// for the place cost as much again as the first for the count.
 __global__ void __launch_bounds__(RT_WG)
-k_cell_place(const unsigned* __restrict__ keys, int n, const int* __restrict__ table, int* __restrict__ hist,
+k_cell_place(const unsigned* __restrict__ keys, int n, const int* __restrict__ table, const int* __restrict__ ranks,
              const float2* __restrict__ rec_in, const float2* __restrict__ ls_in, const int32_t* __restrict__ slot_in,
              float2* __restrict__ rec, float2* __restrict__ ls, int32_t* __restrict__ slot)
 {
     const int j = blockIdx.x * RT_WG + threadIdx.x;
     if (j >= n) return;
     const unsigned key = keys[j];
-    const int at = table[key] + atomicSub(&hist[key], 1) - 1;
+    const int at = table[key] + ranks[j];
     rec[at] = rec_in[j];
     ls[at] = ls_in[j];
     slot[at] = slot_in[j];
@@ -724,7 +725,7 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     temp_bytes = (temp_bytes + 255) & ~(size_t)255;
     const size_t a4 = ((size_t)n * 4 + 255) & ~(size_t)255, a8 = ((size_t)n * 8 + 255) & ~(size_t)255;
     const size_t t4 = (((size_t)fine_cells + 1) * 4 + 255) & ~(size_t)255;
-    RT_TRY(sc->ws_cell_rays.reserve(3 * a4 + 4 * a8));
+    RT_TRY(sc->ws_cell_rays.reserve(4 * a4 + 4 * a8));
     RT_TRY(sc->ws_cell_table.reserve(2 * t4 + temp_bytes));
     RT_TRY(sc->ws_cell_boxes.reserve(sizeof(float4) * (size_t)np * plan->args.sets));
     RT_TRY(sc->ws_cell_wide.reserve(sizeof(int) * (RT_CELLS_WIDE_CAP + 1) * RT_APEX_SETS));
@@ -737,6 +738,7 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     float2* rec = reinterpret_cast<float2*>(ws + 3 * a4 + a8);
     float2* ls_in = reinterpret_cast<float2*>(ws + 3 * a4 + 2 * a8);
     float2* ls = reinterpret_cast<float2*>(ws + 3 * a4 + 3 * a8);
+    int* ranks = reinterpret_cast<int*>(ws + 3 * a4 + 4 * a8);
     int* table = sc->ws_cell_table.as<int>();
     int* hist = reinterpret_cast<int*>(sc->ws_cell_table.as<char>() + t4);
     void* temp = sc->ws_cell_table.as<char>() + 2 * t4;
@@ -753,11 +755,11 @@ int rt_cells_prepare(rt_scene* sc, const SweepArgs& a, const int32_t* lists, con
     unsigned wgs = (unsigned)((largest + RT_WG - 1) / RT_WG);
     if (wgs > 4096) wgs = 4096;
     hipLaunchKernelGGL(k_cell_keys, dim3(wgs, ks.sets), dim3(RT_WG), 0, st, a.S, a.E, lists, a.light_ray_stride,
-                       a.cnt, ks, keys, hist, rec_in, ls_in, slot_in);
+                       a.cnt, ks, keys, hist, ranks, rec_in, ls_in, slot_in);
     RT_HIP(hipGetLastError());
     // table[c] = rays in the fine cells before c, for c = 0 .. fine_cells (the last entry: all of them)
     RT_HIP(rocprim::exclusive_scan(temp, temp_bytes, hist, table, 0, (size_t)fine_cells + 1, rocprim::plus<int>(), st));
-    hipLaunchKernelGGL(k_cell_place, dim3((unsigned)((n + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0, st, keys, n, table, hist,
+    hipLaunchKernelGGL(k_cell_place, dim3((unsigned)((n + RT_WG - 1) / RT_WG)), dim3(RT_WG), 0, st, keys, n, table, ranks,
                        rec_in, ls_in, slot_in, rec, ls, slot);
     RT_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_cell_boxes, dim3((unsigned)((np + RT_WG - 1) / RT_WG), ks.sets), dim3(RT_WG), 0, st, a.planes,
