@@ -255,14 +255,34 @@ k_compact(const int32_t* __restrict__ cnt, const int32_t* __restrict__ in,
     // slice of this workgroup, a multiple of the workgroup size
     const long per = ((long)(n + gridDim.x - 1) / gridDim.x + RT_WG - 1) / RT_WG * RT_WG;
     const long lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
-    auto survivor = [&](long j) {
-        if (j >= hi) return -1;
-        const int id = in ? in[j] : (int)j;
-        return (cnt[id] & (RT_CNT_OCCLUDED | RT_CNT_RETIRED)) ? -1 : id;
+    // kCompactRounds entries per lane at a time, their ray numbers fetched together and then their
+    // states (entry `lo` stands in beyond the slice's end: a fetch under a condition is waited for
+    // inside its branch, and a round of them was two memory round trips in a row for every 256 rays)
+    constexpr int kCompactRounds = 8, WAVES = RT_WG / 64;
+    auto survivors = [&](long j0, int (&id)[kCompactRounds]) {
+        int state[kCompactRounds];
+#pragma unroll
+        for (int r = 0; r < kCompactRounds; ++r) {
+            const long j = j0 + (long)r * RT_WG + threadIdx.x;
+            const long jc = j < hi ? j : lo;
+            id[r] = in ? in[jc] : (int)jc;
+        }
+#pragma unroll
+        for (int r = 0; r < kCompactRounds; ++r) state[r] = cnt[id[r]];
+#pragma unroll
+        for (int r = 0; r < kCompactRounds; ++r) {
+            const bool live = j0 + (long)r * RT_WG + threadIdx.x < hi && !(state[r] & (RT_CNT_OCCLUDED | RT_CNT_RETIRED));
+            id[r] = live ? id[r] : -1;
+        }
     };
     if (!WRITE) {
         int mine = 0;
-        for (long j = lo + threadIdx.x; j - threadIdx.x < hi; j += RT_WG) mine += survivor(j) >= 0;
+        for (long j0 = lo; j0 < hi; j0 += (long)kCompactRounds * RT_WG) {
+            int id[kCompactRounds];
+            survivors(j0, id);
+#pragma unroll
+            for (int r = 0; r < kCompactRounds; ++r) mine += id[r] >= 0;
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
         if (lane == 0) s_wave[wave] = mine;
@@ -301,20 +321,36 @@ k_compact(const int32_t* __restrict__ cnt, const int32_t* __restrict__ in,
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) out_counts[set] = total;
     if (lo >= n) return;
-    for (long j = lo + threadIdx.x; j - threadIdx.x < hi; j += RT_WG) {
-        const int id = survivor(j);
-        const unsigned long long m = __ballot(id >= 0);
-        __syncthreads();                 // s_wave is reused every round
-        if (lane == 0) s_wave[wave] = __popcll(m);
-        __syncthreads();
-        int ahead = 0, round = 0;
+    // a survivor's place: those of the rounds and waves before it (s_round[round][wave], summed
+    // up by the first wave), then those of the lanes before it
+    __shared__ int s_round[kCompactRounds * WAVES + 1];
+    for (long j0 = lo; j0 < hi; j0 += (long)kCompactRounds * RT_WG) {
+        int id[kCompactRounds], ahead[kCompactRounds];
+        survivors(j0, id);
 #pragma unroll
-        for (int k = 0; k < RT_WG / 64; ++k) {
-            ahead += k < wave ? s_wave[k] : 0;
-            round += s_wave[k];
+        for (int r = 0; r < kCompactRounds; ++r) {
+            const unsigned long long m = __ballot(id[r] >= 0);
+            if (lane == 0) s_round[r * WAVES + wave] = __popcll(m);
+            ahead[r] = __popcll(m & ((1ull << lane) - 1));
         }
-        if (id >= 0) out[base + ahead + __popcll(m & ((1ull << lane) - 1))] = id;
-        base += round;
+        __syncthreads();
+        if (wave == 0) {
+            const int c = lane < kCompactRounds * WAVES ? s_round[lane] : 0;
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off);
+                incl += lane >= off ? v : 0;
+            }
+            if (lane < kCompactRounds * WAVES) s_round[lane] = incl - c;
+            if (lane == 63) s_round[kCompactRounds * WAVES] = incl;      // the batch's survivors
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kCompactRounds; ++r)
+            if (id[r] >= 0) out[base + s_round[r * WAVES + wave] + ahead[r]] = id[r];
+        base += s_round[kCompactRounds * WAVES];
+        __syncthreads();                 // s_round is reused by the next batch
     }
 }
 
