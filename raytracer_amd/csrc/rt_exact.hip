@@ -428,20 +428,28 @@ k_try_cached(ExactScene es, const double* __restrict__ Sa, const double* __restr
             const int qx = sx + (kx - LO) * step, qy = wy + ky * step;
             tried[k] = (qx < 0 || qx >= W || qy > last) ? -1 : occ_id[(long)qy * W + qx];
         }
+        // The distinct ones, nearest first.  A lane works through its own list densely -- bit k of
+        // `open` says try k is still to be made, and a triangle that failed is struck out wherever
+        // else it was recorded -- so a wave goes round as often as its unluckiest ray has distinct
+        // candidates, not as often as the positions its lanes' candidates happen to sit at; and
+        // nothing is compared before a try has failed (striking out duplicates up front was 120
+        // comparisons for every ray, most of which are settled by their first try).
+        unsigned open = 0;
 #pragma unroll
-        for (int k = 0; k < NB2; ++k) {
-            const int t = tried[k];
-            if (t < 0 || t >= es.num_tris) continue;
-            bool seen = false;
+        for (int k = 0; k < NB2; ++k) open |= (tried[k] >= 0 && tried[k] < es.num_tris ? 1u : 0u) << k;
+        while (open) {
+            const int k = __builtin_ctz(open);
+            int t = tried[0];
 #pragma unroll
-            for (int m = 0; m < NB2; ++m) seen = seen || (m < k && tried[m] == t);
-            if (seen) continue;
+            for (int m = 1; m < NB2; ++m) t = k == m ? tried[m] : t;
             double u, v;
             if (exact_tri(es, t, S, E, u, v) > 0) {        // triangle_intersection.cu:169
                 atomicOr(&cnt[id], RT_CNT_OCCLUDED);
                 if (record) occ_id[id] = t;
                 break;
             }
+#pragma unroll
+            for (int m = 0; m < NB2; ++m) open &= ~((tried[m] == t ? 1u : 0u) << m);
         }
     }
 }
