@@ -28,6 +28,7 @@ import argparse
 import json
 import math
 import os
+import re
 import sys
 import time
 
@@ -121,6 +122,23 @@ def measured_traffic(workload: str, cfg: str) -> dict | None:
     except OSError:
         return None
     return table.get(f"{workload}/{cfg}")
+
+
+def counted_valu(workload: str, kernel_prefix: str) -> dict | None:
+    """Vector instructions one launch of the primary sweep executes, whole launch (rare path
+    included), as counted by rocprofv3 (SQ_INSTS_VALU of the committed counter pass: counters are
+    collected in runs of their own and cannot be read live).  None when there is no pass for this
+    workload and kernel."""
+    if workload != "soup1m_4k" or not kernel_prefix.startswith("k_sweep_raster_wave"):
+        return None
+    path = os.path.join(ROOT, "profiles", "r03_bench_soup1m_4k", "raster_counters.txt")
+    try:
+        vals = [float(m) for m in re.findall(r"SQ_INSTS_VALU=([0-9.e+]+)", open(path).read())]
+    except OSError:
+        return None
+    if not vals:
+        return None
+    return {"wave_instructions": max(vals), "source": "profiles/r03_bench_soup1m_4k/raster_counters.txt"}
 
 
 def cpu_baseline(mesh, frame, W, H, budget_s: float = 25.0):
@@ -603,6 +621,10 @@ def main() -> None:
                                # the same instruction sequence with nothing around it (no LDS reads,
                                # barriers, branches or rare path), measured by tools/microbench/valu_rate
                                **mix_alone(f"raster{mix_ppl}_wave" if mix_ppl >= 4096 else f"raster{mix_ppl}_box", tests_per_s_launch)},
+                # every vector instruction of the launch (hot loop and rare path), counted by rocprofv3,
+                # against the issue peak over this run's launch time: how busy the vector unit is
+                "valu_issue_whole_launch": (lambda c: {**c, "frac": c["wave_instructions"] * 64 / (sweep_ms_avg * 1e-3) / 1e12 / PEAK_VALU_TINSTR}
+                                            if c and sweep_ms_avg > 0 else None)(counted_valu(args.workload, raster_name)),
                 "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
                 "sweep_kernel": {"tile_tris": tile.value, "pixels_per_lane": ppl.value,
